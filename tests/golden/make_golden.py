@@ -1,0 +1,342 @@
+"""Golden-vector generator.  Runs ONLY in the build container, where /root/reference is mounted.
+
+It imports the unmodified reference (`modeling/`, `diffusion/`) on CPU in fp32, feeds it deterministic
+inputs and deterministic weights (tests/golden/detweights.py), and stores inputs + expected outputs as small
+.npz / .json fixtures next to this file.  Nothing from the reference's source text is stored: fixtures are
+numbers only.  Re-run with:
+
+    PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+REF = os.environ.get("DM_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+from detweights import load_det_weights  # noqa: E402
+
+from modeling import get_model  # noqa: E402  (reference)
+from modeling.blocks import ConvBlock, DownsampleBlock, UpsampleBlock  # noqa: E402
+from modeling.attention import Attention2D  # noqa: E402
+from modeling.embeddings import PeriodicEncoding, MLPEmbedding  # noqa: E402
+from diffusion.scheduler import get_scheduler  # noqa: E402
+from diffusion.sampler import get_sampler  # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+CONFIGS = ["beta_cifar", "cos_cifar", "fid_test", "rf_cifar", "rf_cifar_long", "rf_mnist"]
+
+
+def npz(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, len(out), "arrays")
+
+
+def rnd(rs, *shape, scale=1.0):
+    return torch.from_numpy((rs.standard_normal(shape) * scale).astype(np.float32))
+
+
+# ----------------------------------------------------------------------------------------------
+# 0. configs: copy of the six arg_json files (pure data: the input format the build must load unchanged)
+#    plus the state-dict contract (names, shapes) and parameter counts.
+def dump_configs():
+    os.makedirs(os.path.join(HERE, "arg_json"), exist_ok=True)
+    contract = {}
+    for c in CONFIGS:
+        with open(os.path.join(REF, "arg_json", c + ".json")) as f:
+            cfg = json.load(f)
+        with open(os.path.join(HERE, "arg_json", c + ".json"), "w") as f:
+            json.dump(cfg, f, indent=2)
+        m = get_model(cfg["model_type"], **cfg["model_cfg"])
+        sd = m.state_dict()
+        contract[c] = {
+            "keys": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()],
+            "n_params": sum(p.numel() for p in m.parameters()),
+            "param_names": [k for k, _ in m.named_parameters()],
+        }
+    with open(os.path.join(HERE, "state_dict_contract.json"), "w") as f:
+        json.dump(contract, f)
+    print("wrote state_dict_contract.json", {c: contract[c]["n_params"] for c in CONFIGS})
+
+
+# ----------------------------------------------------------------------------------------------
+# 1. schedules, t_steps grids, timestep embedding
+def dump_schedules():
+    lin = get_scheduler("beta", schedule="linear", n_steps=1000)
+    cos = get_scheduler("beta", schedule="cosine", cos_s=0.008, cos_max_beta=0.999, n_steps=1000)
+    lin_small = get_scheduler("beta", schedule="linear", beta_start=1e-3, beta_end=5e-2, n_steps=37)
+    cos_small = get_scheduler("beta", schedule="cosine", cos_s=0.01, cos_max_beta=0.9, n_steps=50)
+    rf = get_scheduler("rectified_flow", n_steps=1000)
+    rf_small = get_scheduler("rectified_flow", n_steps=13)
+    t = torch.tensor([0, 1, 500, 999])
+    sch = lin.get_schedule(t)
+    grids = {}
+    for n_sched, n in [(1000, 10), (1000, 50), (1000, 1000), (1000, 7), (37, 5), (13, 13), (1000, 1)]:
+        grids[f"tsteps_{n_sched}_{n}"] = torch.linspace(n_sched - 1, 0, steps=n + 1, dtype=torch.int64)[:-1]
+    npz("schedules.npz",
+        lin_beta=lin.beta, lin_alpha_sq=lin.alpha_sq, cos_beta=cos.beta, cos_alpha_sq=cos.alpha_sq,
+        lin_small_beta=lin_small.beta, lin_small_alpha_sq=lin_small.alpha_sq,
+        cos_small_beta=cos_small.beta, cos_small_alpha_sq=cos_small.alpha_sq,
+        rf_sigmas=rf.sigmas, rf_small_sigmas=rf_small.sigmas,
+        sched_t=t, sched_alpha_sq=sch.alpha_sq, sched_sigma_sq=sch.sigma_sq, sched_log_snr=sch.log_snr,
+        **grids)
+
+    ts = torch.tensor([0, 1, 2, 17, 500, 998, 999], dtype=torch.int64)
+    out = {"t": ts}
+    for dim in (64, 128):
+        pe = PeriodicEncoding(dim)
+        out[f"freq_{dim}"] = pe.freq
+        out[f"enc_{dim}"] = pe(ts)
+    mlp = MLPEmbedding(64, 64)
+    load_det_weights(mlp, 11)
+    out["mlp_out_64"] = mlp(out["enc_64"])
+    npz("embeddings.npz", **out)
+
+
+# ----------------------------------------------------------------------------------------------
+# 2. per-layer forward + backward fixtures (weights from detweights seeds)
+def run_fwd_bwd(module, inputs, seed_gy):
+    """inputs: dict name -> tensor (float ones require grad). Returns out, grads of inputs, grads of params."""
+    ins = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in inputs.items()}
+    out = module(**ins)
+    rs = np.random.RandomState(seed_gy)
+    gy = rnd(rs, *out.shape)
+    out.backward(gy)
+    res = {"out": out, "gy": gy}
+    for k, v in ins.items():
+        res["in_" + k] = inputs[k]
+        if v.is_floating_point():
+            res["gin_" + k] = v.grad
+    for k, p in module.named_parameters():
+        res["gp_" + k] = p.grad
+    return res
+
+
+def dump_layers():
+    rs = np.random.RandomState(1234)
+    cases = {}
+    # ConvBlock variants: (cin, cout, emb_dim, mixing, B, H, W)
+    convblock_cases = {
+        "cb_same_ss": (64, 64, 64, "scale_shift", 2, 8, 8),
+        "cb_widen_ss": (64, 128, 64, "scale_shift", 2, 8, 8),
+        "cb_concat_ss": (192, 128, 128, "scale_shift", 2, 4, 4),   # group size 6: vector straddles groups
+        "cb_add": (64, 128, 64, "addition", 2, 8, 8),
+        "cb_noemb": (128, 64, None, "addition", 2, 7, 7),
+        "cb_mnist": (64, 64, 64, "scale_shift", 3, 14, 14),
+    }
+    for i, (name, (cin, cout, emb, mixing, B, H, W)) in enumerate(convblock_cases.items()):
+        m = ConvBlock(cin, cout, norm_groups=32, activation="silu", embedding_dim=emb, embedding_mixing=mixing)
+        load_det_weights(m, 100 + i)
+        ins = {"x": rnd(rs, B, cin, H, W)}
+        if emb is not None:
+            ins["embedding"] = rnd(rs, B, emb)
+        r = run_fwd_bwd(m, ins, 200 + i)
+        r["meta"] = np.array([cin, cout, emb or 0, {"scale_shift": 1, "addition": 0}[mixing], B, H, W, 100 + i])
+        cases[name] = r
+        npz(f"layer_{name}.npz", **r)
+
+    # down / up sample blocks
+    for i, (name, mod, shape) in enumerate([
+        ("down_conv", DownsampleBlock(64, 64, use_conv=True), (2, 64, 16, 16)),
+        ("down_conv_odd", DownsampleBlock(64, 64, use_conv=True), (2, 64, 7, 7)),
+        ("down_pool", DownsampleBlock(64, 64, use_conv=False), (2, 64, 8, 8)),
+        ("up_conv", UpsampleBlock(64, 128, use_conv=True), (2, 64, 4, 4)),
+        ("up_conv_odd", UpsampleBlock(64, 64, use_conv=True), (2, 64, 7, 7)),
+        ("up_noconv", UpsampleBlock(64, 64, use_conv=False), (2, 64, 4, 4)),
+    ]):
+        if len(list(mod.parameters())):
+            load_det_weights(mod, 300 + i)
+        r = run_fwd_bwd(mod, {"x": rnd(rs, *shape)}, 400 + i)
+        r["meta"] = np.array(list(shape) + [300 + i])
+        npz(f"layer_{name}.npz", **r)
+
+    # attention: (n_dim, head_dim, B, H, W)
+    for i, (name, (c, d, B, H, W)) in enumerate({
+        "attn_8x8": (64, 8, 2, 8, 8),
+        "attn_7x7": (128, 8, 2, 7, 7),
+        "attn_16x16_d16": (64, 16, 1, 16, 16),
+    }.items()):
+        m = Attention2D(c, n_dim_head=d, norm_groups=32)
+        load_det_weights(m, 500 + i)
+        m.train()
+        r = run_fwd_bwd(m, {"x": rnd(rs, B, c, H, W)}, 600 + i)
+        r["meta"] = np.array([c, d, B, H, W, 500 + i])
+        npz(f"layer_{name}.npz", **r)
+
+
+# ----------------------------------------------------------------------------------------------
+# 3. whole-UNet fixtures
+TINY_CFG = dict(
+    in_channels=3, out_channels=3,
+    down_block_types=["UNetDownBlock", "UNetDownBlock"], up_block_types=["UNetUpBlock", "UNetUpBlock"],
+    block_out_channels=[64, 128], n_blocks_per_layer=1, mid_attention=True, n_dim_attention_head=8,
+    norm_groups=32, activation="silu", time_encoding_dim=64, embedding_dim=64,
+    embedding_mixing="scale_shift", n_class_embeddings=10, dropout=0.0,
+    downsample_use_conv=True, upsample_use_conv=True,
+)
+TINY_ATTN_CFG = dict(TINY_CFG, down_block_types=["UNetDownBlock", "UNetAttnDownBlock"],
+                     up_block_types=["UNetAttnUpBlock", "UNetUpBlock"], embedding_mixing="addition")
+
+
+def unet_case(name, cfg, seed, B, hw, with_grads=True, store_all_grads=True):
+    m = get_model("unet", **cfg)
+    load_det_weights(m, seed)
+    m.train()
+    rs = np.random.RandomState(seed + 1)
+    cin = cfg["in_channels"]
+    x = rnd(rs, B, cin, hw, hw)
+    t = torch.from_numpy(rs.randint(0, 1000, size=(B,)).astype(np.int64))
+    cls = torch.from_numpy(rs.randint(0, 10, size=(B,)).astype(np.int64))
+    mask = torch.from_numpy((rs.uniform(size=(B,)) < 0.4).astype(np.float32))
+    xg = x.clone().requires_grad_(True)
+    out = m(xg, t, cls=cls, uncond_mask=mask)
+    res = {"x": x, "t": t, "cls": cls, "mask": mask, "out": out, "seed": np.array(seed)}
+    with torch.no_grad():
+        res["out_nocls"] = m(x, t)
+        res["out_nomask"] = m(x, t, cls=cls)
+    if with_grads:
+        gy = rnd(rs, *out.shape)
+        out.backward(gy)
+        res["gy"] = gy
+        res["gx"] = xg.grad
+        names, norms, samples = [], [], []
+        for k, p in m.named_parameters():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            names.append(k)
+            norms.append(float(g.double().norm()))
+            flat = g.flatten()
+            samples.append(flat[:: max(1, flat.numel() // 16)][:16].numpy().copy())
+            if store_all_grads:
+                res["gp_" + k] = g
+        res["grad_norms"] = np.array(norms)
+        res["grad_names"] = np.array(names)
+        res["grad_samples"] = np.stack([np.pad(s, (0, 16 - len(s))) for s in samples])
+    npz(f"unet_{name}.npz", **res)
+    return m
+
+
+def dump_unets():
+    unet_case("tiny", TINY_CFG, 700, 2, 16, store_all_grads=False)
+    unet_case("tiny_attnblocks", TINY_ATTN_CFG, 710, 2, 16, store_all_grads=False)
+    for c, B in [("fid_test", 2), ("rf_mnist", 2), ("cos_cifar", 2)]:
+        with open(os.path.join(REF, "arg_json", c + ".json")) as f:
+            cfg = json.load(f)
+        hw = 28 if c == "rf_mnist" else 32
+        unet_case(c, cfg["model_cfg"], 720 + len(c), B, hw, with_grads=True, store_all_grads=False)
+
+    # classifier-free guidance closure (predictor.py): three branches on the tiny model
+    m = get_model("unet", **TINY_CFG)
+    load_det_weights(m, 700)
+    m.eval()
+    rs = np.random.RandomState(77)
+    z = rnd(rs, 4, 3, 16, 16)
+    t = torch.full((4,), 321, dtype=torch.int64)
+    cls = torch.tensor([1, 5, 9, 0])
+    with torch.no_grad():
+        npz("unet_tiny_cfg.npz", z=z, t=t, cls=cls,
+            g0=m.get_pred_fn(cond=cls, guidance_scale=0.0)(z, t),
+            g1=m.get_pred_fn(cond=cls, guidance_scale=1.0)(z, t),
+            g2=m.get_pred_fn(cond=cls, guidance_scale=2.0)(z, t),
+            gnone=m.get_pred_fn(cond=None, guidance_scale=3.0)(z, t))
+
+
+# ----------------------------------------------------------------------------------------------
+# 4. scheduler losses + samplers with analytic models
+def dump_diffusion():
+    torch.manual_seed(123)
+    z = torch.randn(4, 3, 32, 32)
+    x = torch.rand(8, 3, 32, 32) * 2 - 1
+    res = {"z": z, "x": x}
+    half = lambda x_, t_, **kw: 0.5 * x_
+    scheds = {
+        "lin": get_scheduler("beta", schedule="linear", n_steps=1000),
+        "cos": get_scheduler("beta", schedule="cosine", cos_s=0.008, cos_max_beta=0.999, n_steps=1000),
+        "rf": get_scheduler("rectified_flow", n_steps=1000),
+    }
+    for k, s in scheds.items():
+        gen = torch.Generator().manual_seed(42)
+        res[f"loss_{k}"] = s.get_loss(x, half, gen=gen)
+        gen = torch.Generator().manual_seed(42)
+        eps = torch.randn_like(x, generator=gen)
+        t = torch.randint(0, 1000, size=(8,), generator=gen)
+        res[f"eps_{k}"], res[f"t_{k}"] = eps, t
+        res[f"xt_{k}"] = s.diffuse(x, t, eps)
+    pred = lambda z_, t_: 0.1 * z_ + 1e-6 * t_.view(-1, 1, 1, 1)
+    res["euler50"] = get_sampler("euler", n_steps=50).sample(z, scheds["rf"], pred)
+    res["euler7"] = get_sampler("euler", n_steps=7).sample(z, scheds["rf"], pred)
+    res["ddim50_lin"] = get_sampler("ddim", n_steps=50).sample(z, scheds["lin"], pred)
+    res["ddim50_cos"] = get_sampler("ddim", n_steps=50).sample(z, scheds["cos"], pred)
+    res["ddim10_cos_noclip"] = get_sampler("ddim", n_steps=10, clip_latent=False).sample(z, scheds["cos"], pred)
+    res["ddpm1000_lin"] = get_sampler("ddpm", n_steps=1000).sample(z, scheds["lin"], pred)
+    res["ddpm1000_lin_seed7"] = get_sampler("ddpm", n_steps=1000).sample(z, scheds["lin"], pred, seed=7)
+    res["ddpm20_cos_seed3"] = get_sampler("ddpm", n_steps=20).sample(z, scheds["cos"], pred, seed=3)
+    # the noise the DDPM sampler draws (CPU generator stream), so a device path can be fed the same noise
+    for tag, n, seed in [("ddpm20_cos_seed3", 20, 3)]:
+        gen = torch.Generator()
+        gen.manual_seed(seed)
+        res[f"noise_{tag}"] = torch.stack([torch.randn_like(z, generator=gen) for _ in range(n - 1)])
+    npz("diffusion.npz", **res)
+
+
+# ----------------------------------------------------------------------------------------------
+# 5. train-step fixture: the caller semantics of train.py:429-452 re-stated around the imported reference
+#    (train.py itself needs torchvision/wandb/fire/diffusers, which are absent here).
+def dump_train_steps():
+    m = get_model("unet", **TINY_CFG)
+    load_det_weights(m, 800)
+    m.train()
+    sched = get_scheduler("beta", schedule="cosine", cos_s=0.008, cos_max_beta=0.999, n_steps=1000)
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-4, betas=(0.9, 0.99))
+    rs = np.random.RandomState(801)
+    B, steps = 8, 3
+    res = {"steps": np.array(steps), "seed": np.array(800)}
+    names = [k for k, _ in m.named_parameters()]
+    for s in range(steps):
+        x = torch.from_numpy(rs.uniform(-1, 1, size=(B, 3, 16, 16)).astype(np.float32))
+        cls = torch.from_numpy(rs.randint(0, 10, size=(B,)).astype(np.int64))
+        mask = torch.from_numpy((rs.uniform(size=(B,)) < 0.2).astype(np.float32))
+        eps = rnd(rs, B, 3, 16, 16)
+        t = torch.from_numpy(rs.randint(0, 1000, size=(B,)).astype(np.int64))
+        x_t = sched.diffuse(x, t, eps)
+        pred = m(x_t, t, cls=cls, uncond_mask=mask)
+        loss = torch.nn.functional.mse_loss(pred, eps)
+        loss.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        m.zero_grad()
+        res.update({f"x{s}": x, f"cls{s}": cls, f"mask{s}": mask, f"eps{s}": eps, f"t{s}": t,
+                    f"loss{s}": loss.detach(), f"gnorm{s}": gnorm.detach(), f"xt{s}": x_t})
+        res[f"pnorm{s}"] = np.array([float(p.detach().double().norm()) for p in m.parameters()])
+        res[f"psample{s}"] = np.stack([p.detach().flatten()[:8].numpy().copy() if p.numel() >= 8
+                                       else np.pad(p.detach().flatten().numpy(), (0, 8 - p.numel()))
+                                       for p in m.parameters()])
+    res["param_names"] = np.array(names)
+    npz("train_steps_tiny.npz", **res)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["configs", "schedules", "layers", "unets", "diffusion", "train"]
+    if "configs" in which:
+        dump_configs()
+    if "schedules" in which:
+        dump_schedules()
+    if "layers" in which:
+        dump_layers()
+    if "unets" in which:
+        dump_unets()
+    if "diffusion" in which:
+        dump_diffusion()
+    if "train" in which:
+        dump_train_steps()
