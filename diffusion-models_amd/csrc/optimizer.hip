@@ -1,0 +1,123 @@
+// Optimizer tail on flat fp32 arenas: global gradient norm, and one fused pass for
+// clip -> AdamW (decoupled weight decay, bias correction) -> EMA -> bf16 weight copy.
+// HBM-bound: 4 B/param for the norm, 28 B/param (+12 EMA, +2 bf16) for the update.
+#include "dm_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int NPART = 1024;
+
+__global__ __launch_bounds__(NT) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ partials) {
+  __shared__ float red[NT / 64];
+  float s = 0.f;
+  const long n4 = n >> 2;
+  const f32x4_t* g4 = (const f32x4_t*)g;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+    const f32x4_t v = g4[i];
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0) for (long i = (n4 << 2) + threadIdx.x; i < n; i += NT) s += g[i] * g[i];
+  s = dm_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(NT) void norm_final_kernel(const float* __restrict__ partials, int np, float* __restrict__ out) {
+  __shared__ double red[NT];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < np; i += NT) s += (double)partials[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = NT / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)sqrt(red[0]);
+}
+
+__global__ __launch_bounds__(NT) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, float* __restrict__ ema, bf16_t* __restrict__ wb,
+                                                       const float* __restrict__ norm, float max_norm, long n, float lr,
+                                                       float b1, float b2, float eps, float wd, float bc1, float bc2,
+                                                       float ema_decay, const float* __restrict__ hyper) {
+  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; ema_decay = hyper[3]; }
+  float clip = 1.f;
+  if (max_norm > 0.f && norm) {
+    clip = max_norm / (norm[0] + 1e-6f);
+    clip = clip < 1.f ? clip : 1.f;
+  }
+  const float step_size = lr / bc1;
+  const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  const float omd = 1.f - ema_decay;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const float gi = g[i] * clip;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (ema) { const float e = ema[i]; ema[i] = e - omd * (e - pi); }
+    if (wb) wb[i] = (bf16_t)pi;
+  }
+}
+
+// advances the step counter and derives the step-dependent scalars on the device, so a captured HIP graph of a
+// whole training step can be replayed: hyper = {lr, 1 - b1^step, 1 - b2^step, ema_decay}
+__global__ void optimizer_tick_kernel(long long* step, float* hyper, float lr, float b1, float b2, float ema_inv_gamma,
+                                      float ema_power, float ema_max_decay) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long s = step[0] + 1;
+  step[0] = s;
+  hyper[0] = lr;
+  hyper[1] = (float)(1.0 - pow((double)b1, (double)s));
+  hyper[2] = (float)(1.0 - pow((double)b2, (double)s));
+  // warm-up EMA: decay = min(1 - (1 + (s-1)/inv_gamma)^-power, max), 0 on the first step
+  double d = 0.0;
+  if (s > 1) {
+    d = 1.0 - pow(1.0 + (double)(s - 1) / (double)ema_inv_gamma, -(double)ema_power);
+    if (d > (double)ema_max_decay) d = (double)ema_max_decay;
+    if (d < 0.0) d = 0.0;
+  }
+  hyper[3] = (float)d;
+}
+
+}  // namespace
+
+extern "C" int dm_optimizer_tick(long long* step, float* hyper, float lr, float b1, float b2, float ema_inv_gamma,
+                                 float ema_power, float ema_max_decay, void* stream) {
+  DM_REQUIRE(step && hyper, DM_ERR_ARG, "dm_optimizer_tick: null argument");
+  hipLaunchKernelGGL(optimizer_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, hyper, lr, b1, b2, ema_inv_gamma,
+                     ema_power, ema_max_decay);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_sumsq_partials(void) { return NPART; }
+
+extern "C" int dm_grad_norm(const float* g, long n, float* partials, float* norm_out, void* stream) {
+  DM_REQUIRE(g && partials && norm_out && n > 0, DM_ERR_ARG, "dm_grad_norm: bad argument");
+  DM_REQUIRE((uintptr_t)g % 16 == 0, DM_ERR_ARG, "dm_grad_norm: gradient arena must be 16-byte aligned");
+  long gl = ((n >> 2) + NT - 1) / NT;
+  int grid = (int)(gl > NPART ? NPART : (gl < 1 ? 1 : gl));
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, g, n, partials);
+  DM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, partials, grid, norm_out);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* w_bf16, const float* norm,
+                                 float max_norm, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                 float bc2, float ema_decay, const float* hyper, void* stream) {
+  DM_REQUIRE(p && g && m && v && n > 0, DM_ERR_ARG, "dm_adamw_ema_step: bad argument");
+  DM_REQUIRE(!(max_norm > 0.f) || norm, DM_ERR_ARG, "dm_adamw_ema_step: clipping needs the norm");
+  long gl = (n + NT - 1) / NT;
+  int grid = (int)(gl > 4096 ? 4096 : gl);
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16_t*)w_bf16, norm,
+                     max_norm, n, lr, b1, b2, eps, wd, bc1, bc2, ema_decay, hyper);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}

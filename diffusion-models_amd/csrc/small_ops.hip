@@ -1,0 +1,318 @@
+// Small fp32 operators of the embedding path, resampling helpers, weight packing and column sums.
+// All are latency- or HBM-bound and tiny next to the convolutions.
+#include "dm_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---- sinusoidal timestep encoding: out[b] = [sin(t*freq) | cos(t*freq)]
+__global__ void timestep_embed_kernel(const int64_t* __restrict__ t, const float* __restrict__ freq,
+                                      float* __restrict__ out, int B, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i - b * half;
+  const float a = (float)t[b] * freq[k];
+  out[(size_t)b * 2 * half + k] = sinf(a);
+  out[(size_t)b * 2 * half + half + k] = cosf(a);
+}
+
+// ---- y[m][n] = sum_k f(x[m][k]) w[n][k] + bias[n]; block = 64 columns x 16 rows
+constexpr int LIN_ROWS = 16, LIN_COLS = 64;
+__global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int M,
+                                                        int K, int N, int act_in) {
+  extern __shared__ float lds[];
+  float* xs = lds;                    // [LIN_ROWS][K]
+  float* ws = lds + LIN_ROWS * K;     // [LIN_COLS][K+1]
+  const int n0 = blockIdx.x * LIN_COLS, m0 = blockIdx.y * LIN_ROWS;
+  for (int i = threadIdx.x; i < LIN_ROWS * K; i += NT) {
+    const int r = i / K, k = i - r * K;
+    float v = (m0 + r < M) ? x[(size_t)(m0 + r) * K + k] : 0.f;
+    xs[i] = act_in ? dm_silu(v) : v;
+  }
+  for (int i = threadIdx.x; i < LIN_COLS * K; i += NT) {
+    const int c = i / K, k = i - c * K;
+    ws[c * (K + 1) + k] = (n0 + c < N) ? w[(size_t)(n0 + c) * K + k] : 0.f;
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;  // 4 row groups of 4 rows
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < K; ++k) {
+    const float wv = ws[c * (K + 1) + k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += xs[(rg * 4 + r) * K + k] * wv;
+  }
+  if (n0 + c < N) {
+    const float bv = bias ? bias[n0 + c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + rg * 4 + r;
+      if (m < M) y[(size_t)m * N + n0 + c] = acc[r] + bv;
+    }
+  }
+}
+
+// dx[m][k] = f'(x[m][k]) * sum_n dy[m][n] w[n][k]; one block per row m
+__global__ void linear_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                                    float* __restrict__ dx, int M, int K, int N, int act_in) {
+  const int m = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dy[(size_t)m * N + n] * w[(size_t)n * K + k];
+    if (act_in) s *= dm_silu_grad(x[(size_t)m * K + k]);
+    dx[(size_t)m * K + k] = s;
+  }
+}
+
+// dw[n][k] += sum_m dy[m][n] f(x[m][k]); dbias[n] += sum_m dy[m][n]; one block per output row n
+__global__ void linear_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                    float* __restrict__ dbias, int M, int K, int N, int act_in) {
+  const int n = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) {
+      float xv = x[(size_t)m * K + k];
+      s += dy[(size_t)m * N + n] * (act_in ? dm_silu(xv) : xv);
+    }
+    if (dw) dw[(size_t)n * K + k] += s;
+  }
+  if (dbias && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dy[(size_t)m * N + n];
+    dbias[n] += s;
+  }
+}
+
+// ---- class embedding
+__device__ __forceinline__ int class_index(const int64_t* cls, const float* mask, int uncond, int b) {
+  if (!cls) return uncond;
+  if (mask && mask[b] != 0.f) return uncond;
+  return (int)cls[b];
+}
+__global__ void class_embed_add_kernel(float* __restrict__ emb, const float* __restrict__ table,
+                                       const int64_t* __restrict__ cls, const float* __restrict__ mask, int uncond, int B,
+                                       int E) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * E) return;
+  const int b = i / E, e = i - b * E;
+  emb[i] += table[(size_t)class_index(cls, mask, uncond, b) * E + e];
+}
+__global__ void class_embed_bwd_kernel(const float* __restrict__ demb, float* __restrict__ dtable,
+                                       const int64_t* __restrict__ cls, const float* __restrict__ mask, int uncond, int B,
+                                       int E) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * E) return;
+  const int b = i / E, e = i - b * E;
+  const int idx = class_index(cls, mask, uncond, b);
+  if (idx != uncond) atomicAdd(dtable + (size_t)idx * E + e, demb[i]);
+}
+
+// ---- 2x resampling, NHWC bf16, one thread per 8 channels of one OUTPUT pixel
+__global__ void upsample2x_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int VP) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * 4 * H * W * VP;
+  if (i >= total) return;
+  const int v = i % VP;
+  const long p = i / VP;
+  const int ow = p % (2 * W), oh = (p / (2 * W)) % (2 * H), b = p / (4L * H * W);
+  *(bf16x8_t*)(y + p * VP * 8 + v * 8) = *(const bf16x8_t*)(x + (((long)b * H + (oh >> 1)) * W + (ow >> 1)) * VP * 8 + v * 8);
+}
+// dx[h][w] = sum of the 2x2 block of dy; with avg=1 scaled by 1/4 (average pooling forward uses the same gather)
+__global__ void gather2x2_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int B, int H, int W, int VP,
+                                 float k) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * H * W * VP;
+  if (i >= total) return;
+  const int v = i % VP;
+  const long p = i / VP;
+  const int w = p % W, h = (p / W) % H, b = p / ((long)H * W);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+    for (int dw = 0; dw < 2; ++dw) {
+      float f[8];
+      dm_unpack8(*(const bf16x8_t*)(src + (((long)b * 2 * H + 2 * h + dh) * 2 * W + 2 * w + dw) * VP * 8 + v * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] *= k;
+  *(bf16x8_t*)(dst + p * VP * 8 + v * 8) = dm_pack8(acc);
+}
+// dst (2H x 2W) = k * src (H x W) broadcast over 2x2 blocks (average-pool backward, k = 1/4)
+__global__ void scatter2x2_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int B, int H, int W, int VP,
+                                  float k) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * 4 * H * W * VP;
+  if (i >= total) return;
+  const int v = i % VP;
+  const long p = i / VP;
+  const int ow = p % (2 * W), oh = (p / (2 * W)) % (2 * H), b = p / (4L * H * W);
+  float f[8];
+  dm_unpack8(*(const bf16x8_t*)(src + (((long)b * H + (oh >> 1)) * W + (ow >> 1)) * VP * 8 + v * 8), f);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] *= k;
+  *(bf16x8_t*)(dst + p * VP * 8 + v * 8) = dm_pack8(f);
+}
+
+// ---- weight packing: fp32 [Cout][Cin][KH][KW] (strided) -> bf16 [Cout][T][Cin] and bf16 [Cin][T][Cout]
+__global__ void pack_weight_kernel(const float* __restrict__ w, long s_co, long s_ci, long s_kh, long s_kw, int Cout,
+                                   int Cin, int KH, int KW, bf16_t* __restrict__ wf, bf16_t* __restrict__ wd) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int T = KH * KW;
+  if (i >= (long)Cout * T * Cin) return;
+  const int ci = i % Cin;
+  const int tap = (i / Cin) % T;
+  const int co = i / ((long)Cin * T);
+  const int kh = tap / KW, kw = tap - kh * KW;
+  const bf16_t v = (bf16_t)w[co * s_co + ci * s_ci + kh * s_kh + kw * s_kw];
+  if (wf) wf[i] = v;
+  if (wd) wd[((long)ci * T + tap) * Cout + co] = v;
+}
+
+// ---- column sums
+__global__ __launch_bounds__(NT) void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long M,
+                                                         int C, int rows_per_block) {
+  const int VP = C >> 3, PL = NT / VP;
+  const int v = threadIdx.x % VP, pl = threadIdx.x / VP;
+  if (pl >= PL) return;
+  const long m0 = (long)blockIdx.x * rows_per_block;
+  const long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long m = m0 + pl; m < m1; m += PL) {
+    float f[8];
+    dm_unpack8(*(const bf16x8_t*)(x + m * C + 8 * v), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += f[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) atomicAdd(out + 8 * v + j, acc[j]);
+}
+__global__ void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += x[(size_t)r * C + c];
+  out[c] += s;
+}
+
+}  // namespace
+
+extern "C" int dm_timestep_embed(const int64_t* t, const float* freq, float* out, int B, int half, void* stream) {
+  DM_REQUIRE(t && freq && out && B > 0 && half > 0, DM_ERR_ARG, "dm_timestep_embed: bad argument");
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3(dm_cdiv((long)B * half, NT)), dim3(NT), 0, (hipStream_t)stream, t, freq, out, B, half);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act_in,
+                             void* stream) {
+  DM_REQUIRE(x && w && y && M > 0 && K > 0 && N > 0, DM_ERR_ARG, "dm_linear_fwd: bad argument");
+  const int lds = (LIN_ROWS * K + LIN_COLS * (K + 1)) * 4;
+  DM_REQUIRE(lds <= 65536, DM_ERR_UNSUPPORTED, "dm_linear_fwd: K=%d too large for the embedding-path kernel", K);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(dm_cdiv(N, LIN_COLS), dm_cdiv(M, LIN_ROWS)), dim3(NT), lds, (hipStream_t)stream,
+                     x, w, bias, y, M, K, N, act_in);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias, int M,
+                             int K, int N, int act_in, void* stream) {
+  DM_REQUIRE(x && w && dy && M > 0 && K > 0 && N > 0, DM_ERR_ARG, "dm_linear_bwd: bad argument");
+  const int nt = K >= 256 ? 256 : (K >= 128 ? 128 : 64);
+  if (dx) {
+    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(M), dim3(nt), 0, (hipStream_t)stream, x, w, dy, dx, M, K, N, act_in);
+    DM_CHECK_LAUNCH();
+  }
+  if (dw || dbias) {
+    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(N), dim3(nt), 0, (hipStream_t)stream, x, dy, dw, dbias, M, K, N, act_in);
+    DM_CHECK_LAUNCH();
+  }
+  return DM_OK;
+}
+
+extern "C" int dm_class_embed_add(float* emb, const float* table, const int64_t* cls, const float* mask, int uncond_idx,
+                                  int B, int E, void* stream) {
+  DM_REQUIRE(emb && table && B > 0 && E > 0, DM_ERR_ARG, "dm_class_embed_add: bad argument");
+  hipLaunchKernelGGL(class_embed_add_kernel, dim3(dm_cdiv((long)B * E, NT)), dim3(NT), 0, (hipStream_t)stream, emb, table, cls, mask, uncond_idx, B, E);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_class_embed_bwd(const float* demb, float* dtable, const int64_t* cls, const float* mask, int uncond_idx,
+                                  int B, int E, void* stream) {
+  DM_REQUIRE(demb && dtable && B > 0 && E > 0, DM_ERR_ARG, "dm_class_embed_bwd: bad argument");
+  if (!cls) return DM_OK;  // every row maps to the padding index: no gradient
+  hipLaunchKernelGGL(class_embed_bwd_kernel, dim3(dm_cdiv((long)B * E, NT)), dim3(NT), 0, (hipStream_t)stream, demb, dtable, cls, mask, uncond_idx, B, E);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+static int check_resample(const char* who, const void* a, const void* b, int B, int H, int W, int C) {
+  DM_REQUIRE(a && b, DM_ERR_ARG, "%s: null argument", who);
+  DM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, DM_ERR_SHAPE, "%s: bad shape (C must be a multiple of 8)", who);
+  return DM_OK;
+}
+
+extern "C" int dm_upsample2x_fwd(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+  int rc = check_resample("dm_upsample2x_fwd", x, y, B, H, W, C);
+  if (rc) return rc;
+  const long total = (long)B * 4 * H * W * (C / 8);
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(dm_cdiv(total, NT)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, H, W, C / 8);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+extern "C" int dm_upsample2x_bwd(const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
+  int rc = check_resample("dm_upsample2x_bwd", dy, dx, B, H, W, C);
+  if (rc) return rc;
+  const long total = (long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(gather2x2_kernel, dim3(dm_cdiv(total, NT)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C / 8, 1.0f);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+extern "C" int dm_avgpool2x_fwd(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+  int rc = check_resample("dm_avgpool2x_fwd", x, y, B, H, W, C);
+  if (rc) return rc;
+  DM_REQUIRE(H % 2 == 0 && W % 2 == 0, DM_ERR_SHAPE, "dm_avgpool2x_fwd: odd spatial size %dx%d", H, W);
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL(gather2x2_kernel, dim3(dm_cdiv(total, NT)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, H / 2, W / 2, C / 8, 0.25f);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+extern "C" int dm_avgpool2x_bwd(const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
+  int rc = check_resample("dm_avgpool2x_bwd", dy, dx, B, H, W, C);
+  if (rc) return rc;
+  DM_REQUIRE(H % 2 == 0 && W % 2 == 0, DM_ERR_SHAPE, "dm_avgpool2x_bwd: odd spatial size %dx%d", H, W);
+  const long total = (long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(scatter2x2_kernel, dim3(dm_cdiv(total, NT)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)dx, B, H / 2, W / 2, C / 8, 0.25f);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_pack_conv_weight(const float* w, long s_co, long s_ci, long s_kh, long s_kw, int Cout, int Cin, int KH,
+                                   int KW, void* w_fwd, void* w_dgrad, void* stream) {
+  DM_REQUIRE(w && (w_fwd || w_dgrad) && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, DM_ERR_ARG, "dm_pack_conv_weight: bad argument");
+  const long total = (long)Cout * Cin * KH * KW;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(dm_cdiv(total, NT)), dim3(NT), 0, (hipStream_t)stream, w, s_co, s_ci, s_kh, s_kw,
+                     Cout, Cin, KH, KW, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_colsum_bf16(const void* x, float* out, long M, int C, void* stream) {
+  DM_REQUIRE(x && out && M > 0 && C > 0, DM_ERR_ARG, "dm_colsum_bf16: bad argument");
+  DM_REQUIRE(C % 8 == 0 && C / 8 <= NT, DM_ERR_SHAPE, "dm_colsum_bf16: C=%d must be a multiple of 8 and <= %d", C, NT * 8);
+  int rpb = 256;
+  while (dm_cdiv(M, rpb) > 1024) rpb *= 2;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(dm_cdiv(M, rpb)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, out, M, C, rpb);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+extern "C" int dm_colsum_f32(const float* x, float* out, int R, int C, void* stream) {
+  DM_REQUIRE(x && out && R > 0 && C > 0, DM_ERR_ARG, "dm_colsum_f32: bad argument");
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3(dm_cdiv(C, NT)), dim3(NT), 0, (hipStream_t)stream, x, out, R, C);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}

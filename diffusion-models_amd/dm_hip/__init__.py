@@ -1,0 +1,87 @@
+"""ctypes binding of libdm_hip.so (the C ABI declared in include/dm_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc, gfx950). There is no fallback: importing
+this package without the built library raises, and every operator needs a HIP device.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdm_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950). There is no CPU or stock-PyTorch fallback for these operators."
+    )
+
+lib = ctypes.CDLL(LIB_PATH)
+
+c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in
+                ("B", "Hs", "Ws", "C1", "C2", "Cout", "KH", "KW", "stride", "pad", "ups", "transposed", "Ho", "Wo")]
+
+
+class GnDesc(ctypes.Structure):
+    _fields_ = [("B", c_int), ("HW", c_int), ("C1", c_int), ("C2", c_int), ("G", c_int), ("eps", c_float),
+                ("act", c_int), ("has_ss", c_int), ("has_pre", c_int)]
+
+
+P = c_void_p
+_SIGNATURES = {
+    "dm_abi_version": (c_int, []),
+    "dm_conv2d_igemm": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P]),
+    "dm_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
+    "dm_pack_conv_weight": (c_int, [P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, P, P]),
+    "dm_colsum_bf16": (c_int, [P, P, c_long, c_int, P]),
+    "dm_colsum_f32": (c_int, [P, P, c_int, c_int, P]),
+    "dm_in_conv_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "dm_out_conv_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "dm_out_conv_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "dm_edge_conv_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dm_groupnorm_act_fwd": (c_int, [ctypes.POINTER(GnDesc), P, P, P, P, P, P, P, P, P, P]),
+    "dm_groupnorm_act_bwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 17),
+    "dm_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "dm_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "dm_timestep_embed": (c_int, [P, P, P, c_int, c_int, P]),
+    "dm_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dm_linear_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dm_class_embed_add": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "dm_class_embed_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "dm_upsample2x_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "dm_upsample2x_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "dm_avgpool2x_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "dm_avgpool2x_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "dm_diffuse": (c_int, [P, P, P, P, P, P, c_int, c_long, c_int, P]),
+    "dm_mse_partials": (c_int, []),
+    "dm_mse_loss_fwd": (c_int, [P, P, P, P, P, c_long, c_int, P]),
+    "dm_mse_loss_bwd": (c_int, [P, P, P, P, P, c_long, c_int, P]),
+    "dm_sampler_step": (c_int, [P, P, P, c_float, c_float, c_float, c_float, c_int, c_int, c_int, c_long, P]),
+    "dm_cfg_combine": (c_int, [P, P, P, c_float, c_long, P]),
+    "dm_sumsq_partials": (c_int, []),
+    "dm_grad_norm": (c_int, [P, c_long, P, P, P]),
+    "dm_adamw_ema_step": (c_int, [P, P, P, P, P, P, P, c_float, c_long] + [c_float] * 8 + [P, P]),
+    "dm_optimizer_tick": (c_int, [P, P] + [c_float] * 6 + [P]),
+}
+
+EXPORTS = tuple(_SIGNATURES) + ("dm_last_error",)
+
+for _name, (_res, _args) in _SIGNATURES.items():
+    _f = getattr(lib, _name)
+    _f.restype = _res
+    _f.argtypes = _args
+lib.dm_last_error.restype = ctypes.c_char_p
+lib.dm_last_error.argtypes = []
+
+
+class DmHipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    """Map a non-zero dm_status to an exception carrying the library's message."""
+    if rc != 0:
+        raise DmHipError(f"libdm_hip status {rc}: {lib.dm_last_error().decode()}")

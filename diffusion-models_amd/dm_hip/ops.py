@@ -1,0 +1,510 @@
+"""torch.autograd bindings of the libdm_hip operators.
+
+Activations travel between operators as bf16 tensors of logical shape [B, C, H, W] in channels_last memory
+format, i.e. physically pixel-major [B][H][W][C] as the kernels expect; token tensors [B, L, C] are the same
+memory. Parameters stay fp32 in the reference's shapes. Every function here needs a HIP device tensor.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import ConvDesc, GnDesc, check, lib
+
+BF16 = torch.bfloat16
+CL = torch.channels_last
+
+# When True, packed bf16 weight copies are rebuilt on every forward (needed while a whole training step is
+# captured into a HIP graph: the weights change between replays but the Python-side version check runs once).
+FORCE_REPACK = False
+# Bumped by whoever rewrites parameter memory behind torch's back (the fused optimizer kernel); part of the
+# pack cache key, since such writes do not advance tensor._version.
+WEIGHTS_EPOCH = 0
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_device(t, who):
+    if not t.is_cuda:
+        raise RuntimeError(f"{who}: libdm_hip operators run on the GPU only; got a {t.device} tensor "
+                           "(there is no CPU fallback)")
+
+
+def is_nhwc(x):
+    """True if a [B,C,H,W] tensor is dense pixel-major in memory."""
+    if x.dim() != 4:
+        return False
+    B, C, H, W = x.shape
+    return x.stride() == (H * W * C, 1, W * C, C) or x.numel() == 0
+
+
+def as_nhwc(x):
+    """bf16 + pixel-major memory; no copy when the tensor already is."""
+    _require_device(x, "as_nhwc")
+    if x.dtype == BF16 and is_nhwc(x):
+        return x
+    B, C, H, W = x.shape
+    out = torch.empty_strided((B, C, H, W), (H * W * C, 1, W * C, C), dtype=BF16, device=x.device)
+    out.copy_(x)
+    return out
+
+
+def empty_nhwc(B, C, H, W, device):
+    return torch.empty_strided((B, C, H, W), (H * W * C, 1, W * C, C), dtype=BF16, device=device)
+
+
+def f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------------
+class WeightPack:
+    """bf16 copies of one conv/linear weight in the layouts the implicit-GEMM kernels read:
+    forward [Cout][T][Cin] and data-gradient [Cin][T][Cout]."""
+
+    def __init__(self):
+        self.key = None
+        self.w_fwd = None
+        self.w_dgrad = None
+
+    def get(self, weight):
+        w4 = weight if weight.dim() == 4 else weight[:, :, None, None]
+        key = (weight.data_ptr(), weight._version, weight.device, WEIGHTS_EPOCH)
+        if FORCE_REPACK or key != self.key or self.w_fwd is None:
+            Cout, Cin, KH, KW = w4.shape
+            if self.w_fwd is None or self.w_fwd.device != weight.device or self.w_fwd.numel() != w4.numel():
+                self.w_fwd = torch.empty(w4.numel(), dtype=BF16, device=weight.device)
+                self.w_dgrad = torch.empty(w4.numel(), dtype=BF16, device=weight.device)
+            s = w4.stride()
+            src = w4.detach()
+            if src.dtype != torch.float32:
+                src = src.float()
+                s = src.stride()
+            check(lib.dm_pack_conv_weight(src.data_ptr(), s[0], s[1], s[2], s[3], Cout, Cin, KH, KW,
+                                          self.w_fwd.data_ptr(), self.w_dgrad.data_ptr(), _stream()))
+            self.key = key
+        return self.w_fwd, self.w_dgrad
+
+
+def _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, transposed, Ho, Wo):
+    return ConvDesc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, transposed, Ho, Wo)
+
+
+class _ConvFn(Function):
+    """y = conv2d(cat(x1, x2) [nearest-upsampled x2 if ups], weight) + bias + res"""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, res, stride, pad, ups, pack):
+        _require_device(x1, "conv2d")
+        x1 = as_nhwc(x1)
+        x2 = as_nhwc(x2) if x2 is not None else None
+        res = as_nhwc(res) if res is not None else None
+        w4 = weight if weight.dim() == 4 else weight[:, :, None, None]
+        Cout, Cin, KH, KW = w4.shape
+        B, C1, Hs, Ws = x1.shape
+        C2 = x2.shape[1] if x2 is not None else 0
+        if C1 + C2 != Cin:
+            raise RuntimeError(f"conv2d: input has {C1 + C2} channels, weight expects {Cin}")
+        Hi, Wi = Hs << ups, Ws << ups
+        Ho = (Hi + 2 * pad - KH) // stride + 1
+        Wo = (Wi + 2 * pad - KW) // stride + 1
+        w_fwd, _ = pack.get(weight)
+        y = empty_nhwc(B, Cout, Ho, Wo, x1.device)
+        b32 = f32c(bias.detach()) if bias is not None else None
+        d = _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, 0, Ho, Wo)
+        check(lib.dm_conv2d_igemm(ctypes.byref(d), x1.data_ptr(), _p(x2), w_fwd.data_ptr(), _p(b32), _p(res),
+                                  y.data_ptr(), _stream()))
+        ctx.save_for_backward(x1, x2, weight)
+        ctx.cfg = (stride, pad, ups, pack, bias is not None, res is not None, (B, C1, C2, Hs, Ws, Hi, Wi, Ho, Wo))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, weight = ctx.saved_tensors
+        stride, pad, ups, pack, has_bias, has_res, dims = ctx.cfg
+        B, C1, C2, Hs, Ws, Hi, Wi, Ho, Wo = dims
+        w4 = weight if weight.dim() == 4 else weight[:, :, None, None]
+        Cout, Cin, KH, KW = w4.shape
+        dy = as_nhwc(dy)
+        st = _stream()
+        dx1 = dx2 = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            _, w_dgrad = pack.get(weight)
+            dxf = empty_nhwc(B, Cin, Hi, Wi, dy.device)
+            d = _conv_desc(B, Ho, Wo, Cout, 0, Cin, KH, KW, stride, pad, 0, 1, Hi, Wi)
+            check(lib.dm_conv2d_igemm(ctypes.byref(d), dy.data_ptr(), None, w_dgrad.data_ptr(), None, None,
+                                      dxf.data_ptr(), st))
+            if ups:
+                dxs = empty_nhwc(B, Cin, Hs, Ws, dy.device)
+                check(lib.dm_upsample2x_bwd(dxf.data_ptr(), dxs.data_ptr(), B, Hs, Ws, Cin, st))
+                dxf = dxs
+            if x2 is None:
+                dx1 = dxf
+            else:
+                dx1, dx2 = dxf[:, :C1], dxf[:, C1:]
+        if ctx.needs_input_grad[2]:
+            dwf = torch.zeros((Cout, KH, KW, Cin), dtype=torch.float32, device=dy.device)
+            d = _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, 0, Ho, Wo)
+            check(lib.dm_conv2d_wgrad(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(), st))
+            dw = dwf.permute(0, 3, 1, 2)
+            if weight.dim() == 2:
+                dw = dw.reshape(Cout, Cin)
+        if has_bias and ctx.needs_input_grad[3]:
+            db = torch.zeros(Cout, dtype=torch.float32, device=dy.device)
+            check(lib.dm_colsum_bf16(dy.data_ptr(), db.data_ptr(), B * Ho * Wo, Cout, st))
+        dres = dy if (has_res and ctx.needs_input_grad[4]) else None
+        return dx1, dx2, dw, db, dres, None, None, None, None
+
+
+def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0):
+    return _ConvFn.apply(x1, x2, weight, bias, res, stride, pad, ups, pack)
+
+
+# ------------------------------------------------------------------------------------------------------------
+class _GroupNormActFn(Function):
+    @staticmethod
+    def forward(ctx, x1, x2, gamma, beta, ss, pre, G, eps, act):
+        _require_device(x1, "group_norm")
+        x1 = as_nhwc(x1)
+        x2 = as_nhwc(x2) if x2 is not None else None
+        B, C1, H, W = x1.shape
+        C2 = x2.shape[1] if x2 is not None else 0
+        C = C1 + C2
+        g32, b32 = f32c(gamma.detach()), f32c(beta.detach())
+        ss32 = f32c(ss.detach()) if ss is not None else None
+        pre32 = f32c(pre.detach()) if pre is not None else None
+        if ss32 is not None and tuple(ss32.shape) != (B, 2 * C):
+            raise RuntimeError(f"group_norm: scale_shift must be [{B}, {2 * C}], got {tuple(ss32.shape)}")
+        if pre32 is not None and tuple(pre32.shape) != (B, C):
+            raise RuntimeError(f"group_norm: pre_add must be [{B}, {C}], got {tuple(pre32.shape)}")
+        y = empty_nhwc(B, C, H, W, x1.device)
+        mean = torch.empty((B, G), dtype=torch.float32, device=x1.device)
+        rstd = torch.empty((B, G), dtype=torch.float32, device=x1.device)
+        d = GnDesc(B, H * W, C1, C2, G, eps, int(act), int(ss32 is not None), int(pre32 is not None))
+        check(lib.dm_groupnorm_act_fwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
+                                       _p(ss32), _p(pre32), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                       _stream()))
+        ctx.save_for_backward(x1, x2, g32, b32, ss32, pre32, mean, rstd)
+        ctx.cfg = (d, B, C1, C2, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, g32, b32, ss32, pre32, mean, rstd = ctx.saved_tensors
+        d, B, C1, C2, H, W = ctx.cfg
+        C = C1 + C2
+        dy = as_nhwc(dy)
+        dev = dy.device
+        dx1 = empty_nhwc(B, C1, H, W, dev)
+        dx2 = empty_nhwc(B, C2, H, W, dev) if x2 is not None else None
+        dgp = torch.empty((B, C), dtype=torch.float32, device=dev)
+        dbp = torch.empty((B, C), dtype=torch.float32, device=dev)
+        dss = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if ss32 is not None else None
+        dpre = torch.empty((B, C), dtype=torch.float32, device=dev) if pre32 is not None else None
+        st = _stream()
+        check(lib.dm_groupnorm_act_bwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
+                                       _p(ss32), _p(pre32), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), None,
+                                       dx1.data_ptr(), _p(dx2), dgp.data_ptr(), dbp.data_ptr(), _p(dss), _p(dpre),
+                                       st))
+        dgb = torch.zeros((2, C), dtype=torch.float32, device=dev)
+        check(lib.dm_colsum_f32(dgp.data_ptr(), dgb[0].data_ptr(), B, C, st))
+        check(lib.dm_colsum_f32(dbp.data_ptr(), dgb[1].data_ptr(), B, C, st))
+        return dx1, dx2, dgb[0], dgb[1], dss, dpre, None, None, None
+
+
+def group_norm_act(x1, gamma, beta, groups, eps, act, x2=None, scale_shift=None, pre_add=None):
+    return _GroupNormActFn.apply(x1, x2, gamma, beta, scale_shift, pre_add, groups, eps, act)
+
+
+# ------------------------------------------------------------------------------------------------------------
+class _AttentionFn(Function):
+    @staticmethod
+    def forward(ctx, qkv, H, D, scale):
+        _require_device(qkv, "attention")
+        if qkv.dtype != BF16 or not qkv.is_contiguous():
+            qkv = qkv.to(BF16).contiguous()
+        B, L, F = qkv.shape
+        if F != 3 * H * D:
+            raise RuntimeError(f"attention: packed qkv has {F} features, expected 3*{H}*{D}")
+        out = torch.empty((B, L, H * D), dtype=BF16, device=qkv.device)
+        lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+        check(lib.dm_attention_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, L, H, D, scale, _stream()))
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cfg = (B, L, H, D, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        B, L, H, D, scale = ctx.cfg
+        if dout.dtype != BF16 or not dout.is_contiguous():
+            dout = dout.to(BF16).contiguous()
+        dqkv = torch.empty_like(qkv)
+        check(lib.dm_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                   B, L, H, D, scale, _stream()))
+        return dqkv, None, None, None
+
+
+def attention(qkv, n_heads, head_dim, scale=None):
+    return _AttentionFn.apply(qkv, n_heads, head_dim, float(head_dim ** -0.5 if scale is None else scale))
+
+
+# ------------------------------------------------------------------------------------------------------------
+class _LinearFn(Function):
+    """fp32 embedding-path linear: y = f(x) @ w.T + b, f = SiLU if act_in"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act_in):
+        _require_device(x, "linear")
+        x32, w32 = f32c(x), f32c(weight.detach())
+        b32 = f32c(bias.detach()) if bias is not None else None
+        M, K = x32.shape
+        N = w32.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        check(lib.dm_linear_fwd(x32.data_ptr(), w32.data_ptr(), _p(b32), y.data_ptr(), M, K, N, int(act_in), _stream()))
+        ctx.save_for_backward(x32, w32)
+        ctx.cfg = (M, K, N, int(act_in), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x32, w32 = ctx.saved_tensors
+        M, K, N, act_in, has_bias = ctx.cfg
+        dy = f32c(dy)
+        dev = dy.device
+        dx = torch.empty((M, K), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros((N, K), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        db = torch.zeros((N,), dtype=torch.float32, device=dev) if (has_bias and ctx.needs_input_grad[2]) else None
+        check(lib.dm_linear_bwd(x32.data_ptr(), w32.data_ptr(), dy.data_ptr(), _p(dx), _p(dw), _p(db), M, K, N, act_in,
+                                _stream()))
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias, act_in=False):
+    return _LinearFn.apply(x, weight, bias, act_in)
+
+
+def timestep_embed(t, freq):
+    """[sin(t*freq) | cos(t*freq)], fp32 [B, 2*half]; no gradient (t is an integer step index)."""
+    _require_device(freq, "timestep_embed")
+    t64 = t.to(device=freq.device, dtype=torch.int64).contiguous()
+    f32 = f32c(freq)
+    B, half = t64.shape[0], f32.shape[0]
+    out = torch.empty((B, 2 * half), dtype=torch.float32, device=freq.device)
+    check(lib.dm_timestep_embed(t64.data_ptr(), f32.data_ptr(), out.data_ptr(), B, half, _stream()))
+    return out
+
+
+class _ClassEmbedAddFn(Function):
+    @staticmethod
+    def forward(ctx, emb, table, cls, mask, uncond_idx):
+        _require_device(emb, "class_embed_add")
+        out = f32c(emb).clone()
+        t32 = f32c(table.detach())
+        B, E = out.shape
+        cls64 = cls.to(torch.int64).contiguous() if cls is not None else None
+        m32 = mask.to(torch.float32).contiguous() if mask is not None else None
+        check(lib.dm_class_embed_add(out.data_ptr(), t32.data_ptr(), _p(cls64), _p(m32), uncond_idx, B, E, _stream()))
+        ctx.save_for_backward(cls64, m32)
+        ctx.cfg = (uncond_idx, B, E, tuple(table.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cls64, m32 = ctx.saved_tensors
+        uncond_idx, B, E, tshape = ctx.cfg
+        dout = f32c(dout)
+        dtable = None
+        if ctx.needs_input_grad[1]:
+            dtable = torch.zeros(tshape, dtype=torch.float32, device=dout.device)
+            check(lib.dm_class_embed_bwd(dout.data_ptr(), dtable.data_ptr(), _p(cls64), _p(m32), uncond_idx, B, E,
+                                         _stream()))
+        return dout, dtable, None, None, None
+
+
+def class_embed_add(emb, table, cls, mask, uncond_idx):
+    return _ClassEmbedAddFn.apply(emb, table, cls, mask, uncond_idx)
+
+
+# ------------------------------------------------------------------------------------------------------------
+class _InConvFn(Function):
+    """3x3 'same' conv from an NCHW fp32 image to pixel-major bf16 features."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_device(x, "in_conv")
+        x32, w32 = f32c(x), f32c(weight.detach())
+        b32 = f32c(bias.detach()) if bias is not None else None
+        B, Cs, H, W = x32.shape
+        Cb = w32.shape[0]
+        y = empty_nhwc(B, Cb, H, W, x.device)
+        check(lib.dm_in_conv_fwd(x32.data_ptr(), w32.data_ptr(), _p(b32), y.data_ptr(), B, Cs, H, W, Cb, _stream()))
+        ctx.save_for_backward(x32)
+        ctx.cfg = (B, Cs, H, W, Cb, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x32,) = ctx.saved_tensors
+        B, Cs, H, W, Cb, has_bias = ctx.cfg
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("in_conv: gradient w.r.t. the image is not implemented (the reference never needs it)")
+        dy = as_nhwc(dy)
+        dw = torch.zeros((Cb, Cs, 3, 3), dtype=torch.float32, device=dy.device)
+        db = torch.zeros((Cb,), dtype=torch.float32, device=dy.device) if has_bias else None
+        check(lib.dm_edge_conv_wgrad(x32.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(db), B, Cs, H, W, Cb, 1, _stream()))
+        return None, dw, db
+
+
+def in_conv(x, weight, bias):
+    return _InConvFn.apply(x, weight, bias)
+
+
+class _OutConvFn(Function):
+    """3x3 'same' conv from pixel-major bf16 features to an NCHW fp32 image."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias):
+        _require_device(h, "out_conv")
+        h = as_nhwc(h)
+        w32 = f32c(weight.detach())
+        b32 = f32c(bias.detach()) if bias is not None else None
+        B, Cb, H, W = h.shape
+        Cs = w32.shape[0]
+        y = torch.empty((B, Cs, H, W), dtype=torch.float32, device=h.device)
+        check(lib.dm_out_conv_fwd(h.data_ptr(), w32.data_ptr(), _p(b32), y.data_ptr(), B, Cs, H, W, Cb, _stream()))
+        ctx.save_for_backward(h, w32)
+        ctx.cfg = (B, Cs, H, W, Cb, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w32 = ctx.saved_tensors
+        B, Cs, H, W, Cb, has_bias = ctx.cfg
+        dy = f32c(dy)
+        st = _stream()
+        dh = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dh = empty_nhwc(B, Cb, H, W, dy.device)
+            check(lib.dm_out_conv_dgrad(dy.data_ptr(), w32.data_ptr(), dh.data_ptr(), B, Cs, H, W, Cb, st))
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((Cs, Cb, 3, 3), dtype=torch.float32, device=dy.device)
+            db = torch.zeros((Cs,), dtype=torch.float32, device=dy.device) if has_bias else None
+            check(lib.dm_edge_conv_wgrad(dy.data_ptr(), h.data_ptr(), dw.data_ptr(), _p(db), B, Cs, H, W, Cb, 0, st))
+        return dh, dw, db
+
+
+def out_conv(h, weight, bias):
+    return _OutConvFn.apply(h, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------------------
+class _Resample2xFn(Function):
+    """mode 'up': nearest x2 upsampling; mode 'avg': 2x2 average pooling. bf16 pixel-major."""
+
+    @staticmethod
+    def forward(ctx, x, mode):
+        _require_device(x, "resample2x")
+        x = as_nhwc(x)
+        B, C, H, W = x.shape
+        st = _stream()
+        if mode == "up":
+            y = empty_nhwc(B, C, 2 * H, 2 * W, x.device)
+            check(lib.dm_upsample2x_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, st))
+        else:
+            y = empty_nhwc(B, C, H // 2, W // 2, x.device)
+            check(lib.dm_avgpool2x_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, st))
+        ctx.cfg = (mode, B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        mode, B, C, H, W = ctx.cfg
+        dy = as_nhwc(dy)
+        dx = empty_nhwc(B, C, H, W, dy.device)
+        st = _stream()
+        if mode == "up":
+            check(lib.dm_upsample2x_bwd(dy.data_ptr(), dx.data_ptr(), B, H, W, C, st))
+        else:
+            check(lib.dm_avgpool2x_bwd(dy.data_ptr(), dx.data_ptr(), B, H, W, C, st))
+        return dx, None
+
+
+def upsample2x(x):
+    return _Resample2xFn.apply(x, "up")
+
+
+def avgpool2x(x):
+    return _Resample2xFn.apply(x, "avg")
+
+
+# ------------------------------------------------------------------------------------------------------------
+def diffuse(x, eps, t, tab64=None, tab32=None):
+    """x_t = a[t] x + s[t] eps with (a, s) from the variance-preserving table (fp64 alpha_sq) or the
+    rectified-flow sigmas (fp32)."""
+    _require_device(x, "diffuse")
+    x32, e32 = f32c(x), f32c(eps)
+    t64 = t.to(device=x.device, dtype=torch.int64).contiguous()
+    B = x32.shape[0]
+    n = x32.numel() // B
+    out = torch.empty_like(x32)
+    mode = 0 if tab64 is not None else 1
+    check(lib.dm_diffuse(x32.data_ptr(), e32.data_ptr(), t64.data_ptr(), _p(tab64), _p(tab32), out.data_ptr(), B, n,
+                         mode, _stream()))
+    return out
+
+
+class _MseLossFn(Function):
+    """mean((pred - target)^2); target = eps (mode 0) or x - eps (mode 1)"""
+
+    @staticmethod
+    def forward(ctx, pred, x, eps, mode):
+        _require_device(pred, "mse_loss")
+        p32, e32 = f32c(pred), f32c(eps)
+        x32 = f32c(x) if x is not None else None
+        partials = torch.empty(lib.dm_mse_partials(), dtype=torch.float32, device=pred.device)
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        check(lib.dm_mse_loss_fwd(p32.data_ptr(), _p(x32), e32.data_ptr(), partials.data_ptr(), loss.data_ptr(),
+                                  p32.numel(), mode, _stream()))
+        ctx.save_for_backward(p32, x32, e32)
+        ctx.mode = mode
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        p32, x32, e32 = ctx.saved_tensors
+        g = f32c(gout).reshape(1)
+        dpred = torch.empty_like(p32)
+        check(lib.dm_mse_loss_bwd(p32.data_ptr(), _p(x32), e32.data_ptr(), g.data_ptr(), dpred.data_ptr(), p32.numel(),
+                                  ctx.mode, _stream()))
+        return dpred, None, None, None
+
+
+def mse_loss(pred, eps, x=None, mode=0):
+    return _MseLossFn.apply(pred, x, eps, mode)
+
+
+def sampler_step(z, pred, noise, c0, c1, c2, c3, mode, clip, last):
+    """In-place sampler update on z (fp32, contiguous)."""
+    _require_device(z, "sampler_step")
+    if z.dtype != torch.float32 or not z.is_contiguous():
+        raise RuntimeError("sampler_step: z must be a contiguous fp32 tensor")
+    p32 = f32c(pred)
+    n32 = f32c(noise) if noise is not None else None
+    check(lib.dm_sampler_step(z.data_ptr(), p32.data_ptr(), _p(n32), c0, c1, c2, c3, mode, int(clip), int(last),
+                              z.numel(), _stream()))
+    return z
+
+
+def cfg_combine(pred_uncond, pred_cond, scale):
+    _require_device(pred_uncond, "cfg_combine")
+    u, c = f32c(pred_uncond), f32c(pred_cond)
+    out = torch.empty_like(u)
+    check(lib.dm_cfg_combine(u.data_ptr(), c.data_ptr(), out.data_ptr(), float(scale), u.numel(), _stream()))
+    return out

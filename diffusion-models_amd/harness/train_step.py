@@ -1,0 +1,183 @@
+"""The training step of the reference's Trainer.train_on_batch (train.py:429-452), as a reusable harness.
+
+    uncond_mask = bernoulli(p_uncond)            RNG draw 1
+    loss = scheduler.get_loss(x, model, ...)     RNG draws 2 (eps) and 3 (t)
+    loss.backward()
+    clip_grad_norm_(params, max_norm)            global L2 norm over all parameters
+    AdamW(lr, betas, eps=1e-8, weight_decay=1e-2).step(); zero_grad(); EMA.step()
+
+MI355X-first layout: all parameters live in ONE flat fp32 arena (the nn.Parameters are views into it), and so
+do gradients, Adam moments and the EMA shadow. The optimizer tail is then two kernels over contiguous memory
+(norm, fused clip+AdamW+EMA) instead of ~660 per-tensor launches, and data-parallel gradient averaging is an
+all-reduce over contiguous slices of the gradient arena, launched bucket by bucket (reverse registration order,
+the order gradients become ready) while backward is still running.
+"""
+import ctypes
+import math
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from dm_hip import check, lib, ops
+from modeling.layers import Conv2d
+
+_ALIGN = 64  # floats: every parameter starts on a 256-byte boundary
+
+
+class FlatArena:
+    """Parameters of a module re-homed into one contiguous fp32 buffer, in registration order."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        device = self.params[0][1].device
+        conv_weights = {id(m.weight) for m in module.modules() if isinstance(m, Conv2d)}
+        self.offsets, off = [], 0
+        for _, p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.names = [n for n, _ in self.params]
+        for (n, p), o in zip(self.params, self.offsets):
+            if id(p) in conv_weights and p.dim() == 4:
+                # physical [Cout][KH][KW][Cin]: the layout the weight-gradient kernel produces
+                co, ci, kh, kw = p.shape
+                view = self.data[o:o + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+                gview = self.grad[o:o + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+            else:
+                view = self.data[o:o + p.numel()].view(p.shape)
+                gview = self.grad[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = gview
+
+    def grad_slices(self, bucket_bytes: int):
+        """Contiguous [start, end) element ranges of the gradient arena, walking parameters in REVERSE
+        registration order, each about bucket_bytes; with the index of the first-registered parameter of each."""
+        buckets, end, cur_first = [], self.numel, None
+        limit = max(1, bucket_bytes // 4)
+        hi = self.numel
+        for i in range(len(self.params) - 1, -1, -1):
+            start = self.offsets[i]
+            if hi - start >= limit or i == 0:
+                buckets.append((start, hi, i))
+                hi = start
+        return buckets
+
+
+class TrainStep:
+    def __init__(self, model, scheduler, lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2,
+                 clip_grad_norm: Optional[float] = 1.0, use_ema=True, ema_inv_gamma=1.0, ema_power=0.75,
+                 ema_max_decay=0.9999, p_uncond=0.2, bucket_mb=25, process_group=None):
+        self.model, self.scheduler = model, scheduler
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.clip = float(clip_grad_norm) if clip_grad_norm else 0.0
+        self.p_uncond = p_uncond
+        self.ema_cfg = (ema_inv_gamma, ema_power, ema_max_decay)
+        self.arena = FlatArena(model)
+        dev = self.arena.data.device
+        n = self.arena.numel
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.ema = self.arena.data.clone() if use_ema else None
+        self.partials = torch.empty(lib.dm_sumsq_partials(), dtype=torch.float32, device=dev)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.steps = 0
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._buckets = self.arena.grad_slices(bucket_mb << 20)
+        self._handles = []
+        if self.world > 1:
+            self._install_overlap_hooks()
+
+    # ---- data-parallel gradient averaging, overlapped with backward --------------------------------------
+    def _install_overlap_hooks(self):
+        first_param_to_bucket = {first: b for b, (_, _, first) in enumerate(self._buckets)}
+        params = self.arena.params
+
+        def make_hook(idx):
+            def hook(_p):
+                # Gradients arrive in reverse registration order; when the FIRST-registered parameter of a bucket
+                # has its gradient, the whole contiguous slice is final and its all-reduce can start.
+                b = first_param_to_bucket.get(idx)
+                if b is not None and self._overlap_enabled:
+                    self._launch_bucket(b)
+            return hook
+
+        self._overlap_enabled = True
+        for i, (_, p) in enumerate(params):
+            p.register_post_accumulate_grad_hook(make_hook(i))
+
+    def _launch_bucket(self, b):
+        lo, hi, _ = self._buckets[b]
+        self._handles.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                             async_op=True))
+        self._launched.add(b)
+
+    def _finish_allreduce(self):
+        if self.world == 1:
+            return
+        for b in range(len(self._buckets)):  # parameters that received no gradient never fired their hook
+            if b not in self._launched:
+                self._launch_bucket(b)
+        for h in self._handles:
+            h.wait()
+        self._handles.clear()
+        self.arena.grad.mul_(1.0 / self.world)
+
+    # ---- one step ----------------------------------------------------------------------------------------
+    def _backward_and_update(self, loss):
+        self._launched = set()
+        loss.backward()
+        self._finish_allreduce()
+        a = self.arena
+        st = torch.cuda.current_stream().cuda_stream
+        if self.clip > 0:
+            check(lib.dm_grad_norm(a.grad.data_ptr(), a.numel, self.partials.data_ptr(), self.norm.data_ptr(), st))
+        ig, pw, mx = self.ema_cfg
+        check(lib.dm_optimizer_tick(self.step_dev.data_ptr(), self.hyper.data_ptr(), self.lr, self.betas[0],
+                                    self.betas[1], ig, pw, mx, st))
+        check(lib.dm_adamw_ema_step(a.data.data_ptr(), a.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                    self.ema.data_ptr() if self.ema is not None else None, None,
+                                    self.norm.data_ptr() if self.clip > 0 else None, self.clip, a.numel, self.lr,
+                                    self.betas[0], self.betas[1], self.eps, self.wd, 1.0, 1.0, 0.0,
+                                    self.hyper.data_ptr(), st))
+        a.grad.zero_()
+        self.steps += 1
+        ops.WEIGHTS_EPOCH += 1  # packed bf16 copies of the weights are stale now
+
+    def step(self, x, label=None):
+        """train.py:429-452. Returns the loss tensor (device scalar; call .item() to mirror the reference's sync)."""
+        uncond_mask = None
+        if label is not None:
+            uncond_mask = torch.bernoulli(self.p_uncond * torch.ones_like(label))
+        loss = self.scheduler.get_loss(x, self.model, cls=label, uncond_mask=uncond_mask)
+        self._backward_and_update(loss)
+        return loss.detach()
+
+    def step_given_noise(self, x, label, uncond_mask, eps, t):
+        """Same step with the random draws supplied by the caller (parity tests)."""
+        x_t = self.scheduler.diffuse(x, t, eps)
+        pred = self.model(x_t, t, cls=label, uncond_mask=uncond_mask)
+        if self.scheduler.pred_type == "velocity":
+            loss = ops.mse_loss(pred, eps, x=x, mode=1)
+        else:
+            loss = ops.mse_loss(pred, eps, mode=0)
+        self._backward_and_update(loss)
+        return loss.detach(), self.norm.clone()
+
+    # ---- EMA weights in / out (train.py:363-373 saves model.pt and ema_model.pt) ---------------------------
+    def ema_state_dict(self):
+        sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        for (n, p), o in zip(self.arena.params, self.arena.offsets):
+            flat = self.ema[o:o + p.numel()]
+            if p.dim() == 4 and not p.is_contiguous():
+                co, ci, kh, kw = p.shape
+                sd[n] = flat.view(co, kh, kw, ci).permute(0, 3, 1, 2).contiguous()
+            else:
+                sd[n] = flat.view(p.shape).clone()
+        return sd

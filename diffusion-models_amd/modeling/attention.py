@@ -1,0 +1,43 @@
+"""Spatial self-attention layer (reference: modeling/attention.py:35-84)."""
+from typing import Optional
+
+import torch
+from torch import nn
+
+from dm_hip import ops
+from modeling.layers import GroupNorm, Linear
+
+
+class Attention2D(nn.Module):
+    def __init__(self, n_dim: int, n_heads: Optional[int] = None, n_dim_head: Optional[int] = None,
+                 norm_groups: int = 32, dropout: float = 0.0):
+        super().__init__()
+        assert n_dim_head is not None or n_heads is not None
+        if n_dim_head is None:
+            assert n_dim % n_heads == 0
+            n_dim_head = n_dim // n_heads
+        elif n_heads is None:
+            assert n_dim % n_dim_head == 0
+            n_heads = n_dim // n_dim_head
+        self.n_heads = n_heads
+        self.n_dim_head = n_dim_head
+        self.n_dim_inner = n_heads * n_dim_head
+        self._dropout = float(dropout)
+        self.register_buffer("dropout_p", torch.tensor(dropout))
+
+        self.norm = GroupNorm(norm_groups, n_dim)
+        self.qkv_proj = Linear(n_dim, 3 * self.n_dim_inner)
+        self.out_proj = Linear(self.n_dim_inner, n_dim)
+
+    def forward(self, x: torch.Tensor):
+        if self.training and self._dropout > 0:
+            raise NotImplementedError("Attention2D: attention dropout > 0 is not implemented in the HIP kernels")
+        B, C, H, W = x.shape
+        L = H * W
+        x = ops.as_nhwc(x)
+        h = self.norm(x)                                  # [B, C, H, W] pixel-major == tokens [B, L, C]
+        qkv = self.qkv_proj(h)                            # [B, 3*inner, H, W] == tokens [B, L, (3, heads, d)]
+        tokens = qkv.permute(0, 2, 3, 1).reshape(B, L, 3 * self.n_dim_inner)
+        att = ops.attention(tokens, self.n_heads, self.n_dim_head)      # [B, L, inner]
+        att = att.view(B, H, W, self.n_dim_inner).permute(0, 3, 1, 2)   # pixel-major view, no copy
+        return self.out_proj(att, res=x)

@@ -1,0 +1,374 @@
+"""Residual / resampling / stage blocks of the UNet (reference: modeling/blocks.py).
+
+Same class names, constructor arguments, sub-module names and registration order as the reference, so state
+dicts are interchangeable. Differences are internal: activations are bf16 pixel-major tensors, GroupNorm+SiLU
+(+ scale/shift) is one kernel, the residual add rides in the conv epilogue, the skip concatenation and the
+nearest-neighbour upsampling are fused into the consuming kernels' gathers instead of being materialised.
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from dm_hip import ops
+from modeling.activation import get_activation, is_silu
+from modeling.attention import Attention2D
+from modeling.layers import Conv2d, EmbLinear, GroupNorm
+
+
+class ConvBlock(nn.Module):
+    """GN-act-conv3x3, embedding mix, GN-act-(dropout)-conv3x3, plus (projected) residual
+    (reference: modeling/blocks.py:10-75). `skip`, when given, is a second input concatenated after `x` on the
+    channel axis (what the reference's up blocks pass as torch.cat([x, skip], 1))."""
+
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, norm_groups: int = 32,
+                 activation: str = "swish", embedding_dim: Optional[int] = None,
+                 embedding_mixing: str = "addition", dropout: float = 0.0):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        self.embedding_mixing = embedding_mixing
+
+        self.norm1 = GroupNorm(norm_groups, in_channels)
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=3, padding="same")
+        self.norm2 = GroupNorm(norm_groups, out_channels)
+        self.conv2 = Conv2d(out_channels, out_channels, kernel_size=3, padding="same")
+
+        if embedding_dim is None:
+            self.emb_proj = None
+        elif embedding_mixing == "addition":
+            self.emb_proj = EmbLinear(embedding_dim, out_channels)
+        elif embedding_mixing == "scale_shift":
+            self.emb_proj = EmbLinear(embedding_dim, out_channels * 2)
+        else:
+            raise ValueError(f'unknown embedding mixing "{embedding_mixing}"')
+
+        self.nonlinearity = get_activation(activation)
+        self.dropout = nn.Dropout(dropout)
+        if in_channels == out_channels:
+            self.res_proj = nn.Identity()
+        else:
+            self.res_proj = Conv2d(in_channels, out_channels, kernel_size=1)
+
+    def _norm_act(self, norm, x, **kw):
+        if is_silu(self.nonlinearity):
+            return norm(x, act=True, **kw)
+        return self.nonlinearity(norm(x, act=False, **kw))
+
+    def forward(self, x: torch.Tensor, embedding: Optional[torch.Tensor] = None,
+                skip: Optional[torch.Tensor] = None):
+        x = ops.as_nhwc(x)
+        skip = ops.as_nhwc(skip) if skip is not None else None
+
+        h = self._norm_act(self.norm1, x, x2=skip)
+        h = self.conv1(h)
+
+        mix = {}
+        if self.emb_proj is not None:
+            assert embedding is not None
+            if is_silu(self.nonlinearity):
+                e = self.emb_proj(embedding, act_in=True)
+            else:
+                e = self.emb_proj(self.nonlinearity(embedding))
+            mix = {"pre_add": e} if self.embedding_mixing == "addition" else {"scale_shift": e}
+        h = self._norm_act(self.norm2, h, **mix)
+        if self.training and self.dropout.p > 0:
+            h = self.dropout(h)
+
+        if isinstance(self.res_proj, nn.Identity):
+            res = x if skip is None else torch.cat([x, skip], dim=1)
+        else:
+            res = self.res_proj(x, x2=skip)
+        return self.conv2(h, res=res)
+
+
+class DownsampleBlock(nn.Module):
+    """Stride-2 3x3 conv (pad 1) or 2x2 average pooling (reference: modeling/blocks.py:78-96)."""
+
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, use_conv: bool = True):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        if use_conv:
+            self.conv = Conv2d(in_channels, out_channels, kernel_size=3, stride=2, padding=1)
+        else:
+            assert in_channels == out_channels
+            self.conv = nn.AvgPool2d(kernel_size=2, stride=2)
+
+    def forward(self, x):
+        if isinstance(self.conv, Conv2d):
+            return self.conv(x)
+        return ops.avgpool2x(x)
+
+
+class UpsampleBlock(nn.Module):
+    """Nearest x2 upsampling followed by a 3x3 conv; the upsampled tensor is never written: the conv gathers
+    from the low-resolution source (reference: modeling/blocks.py:99-119)."""
+
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, use_conv: bool = True):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        if use_conv:
+            self.conv = Conv2d(in_channels, out_channels, kernel_size=3, padding="same")
+        else:
+            assert in_channels == out_channels
+            self.conv = None
+
+    def forward(self, x):
+        if self.conv is None:
+            return ops.upsample2x(x)
+        return self.conv(x, ups=1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Stages. The eight public classes differ only in (a) attention after each ConvBlock, (b) whether a timestep
+# embedding is consumed, (c) whether skips are produced/consumed; the shared plumbing lives in two bases whose
+# sub-modules are registered in the reference's order: blocks, [attentions], downsample|upsample.
+class _DownStage(nn.Module):
+    _with_attention = False
+    _with_embedding = True
+
+    def __init__(self, in_channels: int, out_channels: int, n_blocks: int = 2, n_heads: Optional[int] = None,
+                 n_dim_head: Optional[int] = None, norm_groups: int = 32, activation: str = "swish",
+                 embedding_dim: Optional[int] = None, embedding_mixing: str = "addition", dropout: float = 0.0,
+                 downsample: bool = True, downsample_use_conv: bool = True):
+        super().__init__()
+        emb = embedding_dim if self._with_embedding else None
+        mixing = {"embedding_mixing": embedding_mixing} if self._with_embedding else {}
+        self.blocks = nn.ModuleList(
+            ConvBlock(in_channels if i == 0 else out_channels, out_channels=out_channels, norm_groups=norm_groups,
+                      activation=activation, embedding_dim=emb, dropout=dropout, **mixing)
+            for i in range(n_blocks))
+        if self._with_attention:
+            self.attentions = nn.ModuleList(
+                Attention2D(out_channels, n_heads=n_heads, n_dim_head=n_dim_head, norm_groups=norm_groups,
+                            dropout=dropout) for _ in range(n_blocks))
+        self.downsample = DownsampleBlock(out_channels, out_channels, use_conv=downsample_use_conv) \
+            if downsample else None
+
+    def _run(self, x, embedding):
+        outs = []
+        for i, block in enumerate(self.blocks):
+            x = block(x, embedding=embedding) if self._with_embedding else block(x)
+            if self._with_attention:
+                x = self.attentions[i](x)
+            outs.append(x)
+        if self.downsample is not None:
+            x = self.downsample(x)
+            outs.append(x)
+        return x, tuple(outs)
+
+
+class _UpStage(nn.Module):
+    _with_attention = False
+    _with_embedding = True   # embedding-consuming stages also consume skips
+
+    def __init__(self, in_channels: int, out_channels: int, next_out_channels: Optional[int] = None,
+                 n_blocks: int = 2, n_heads: Optional[int] = None, n_dim_head: Optional[int] = None,
+                 norm_groups: int = 32, activation: str = "swish", embedding_dim: Optional[int] = None,
+                 embedding_mixing: str = "addition", dropout: float = 0.0, upsample: bool = True,
+                 upsample_use_conv: bool = True):
+        super().__init__()
+        blocks = []
+        for i in range(n_blocks):
+            cin = in_channels if i == 0 else out_channels
+            if self._with_embedding:
+                cin += out_channels if i < n_blocks - 1 else next_out_channels
+                blocks.append(ConvBlock(cin, out_channels=out_channels, norm_groups=norm_groups,
+                                        activation=activation, embedding_dim=embedding_dim,
+                                        embedding_mixing=embedding_mixing, dropout=dropout))
+            else:
+                blocks.append(ConvBlock(cin, out_channels=out_channels, norm_groups=norm_groups,
+                                        activation=activation, embedding_dim=None, dropout=dropout))
+        self.blocks = nn.ModuleList(blocks)
+        if self._with_attention:
+            self.attentions = nn.ModuleList(
+                Attention2D(out_channels, n_heads=n_heads, n_dim_head=n_dim_head, norm_groups=norm_groups,
+                            dropout=dropout) for _ in range(n_blocks))
+        self.upsample = UpsampleBlock(out_channels, out_channels, use_conv=upsample_use_conv) if upsample else None
+
+    def _run(self, x, skips, embedding):
+        if skips is not None:
+            skips = tuple(reversed(skips))[:len(self.blocks)]
+        for i, block in enumerate(self.blocks):
+            if skips is not None:
+                if i >= len(skips):
+                    break  # zip() semantics of the reference: stop at the shorter sequence
+                x = block(x, embedding=embedding, skip=skips[i])
+            else:
+                x = block(x)
+            if self._with_attention:
+                x = self.attentions[i](x)
+        if self.upsample is not None:
+            x = self.upsample(x)
+        return x
+
+
+class UNetDownBlock(_DownStage):
+    def __init__(self, in_channels, out_channels, n_blocks=2, norm_groups=32, activation="swish",
+                 embedding_dim=None, embedding_mixing="addition", dropout=0.0, downsample=True,
+                 downsample_use_conv=True):
+        super().__init__(in_channels, out_channels, n_blocks=n_blocks, norm_groups=norm_groups,
+                         activation=activation, embedding_dim=embedding_dim, embedding_mixing=embedding_mixing,
+                         dropout=dropout, downsample=downsample, downsample_use_conv=downsample_use_conv)
+
+    def forward(self, x: torch.Tensor, embedding: Optional[torch.Tensor] = None):
+        return self._run(x, embedding)
+
+
+class UNetAttnDownBlock(_DownStage):
+    _with_attention = True
+
+    def forward(self, x: torch.Tensor, embedding: Optional[torch.Tensor] = None):
+        return self._run(x, embedding)
+
+
+class EncoderDownBlock(_DownStage):
+    _with_embedding = False
+
+    def __init__(self, in_channels, out_channels, n_blocks=2, norm_groups=32, activation="swish", dropout=0.0,
+                 downsample=True, downsample_use_conv=True):
+        super().__init__(in_channels, out_channels, n_blocks=n_blocks, norm_groups=norm_groups,
+                         activation=activation, dropout=dropout, downsample=downsample,
+                         downsample_use_conv=downsample_use_conv)
+
+    def forward(self, x: torch.Tensor):
+        return self._run(x, None)[0]
+
+
+class EncoderAttnDownBlock(_DownStage):
+    _with_attention = True
+    _with_embedding = False
+
+    def __init__(self, in_channels, out_channels, n_blocks=2, n_heads=None, n_dim_head=None, norm_groups=32,
+                 activation="swish", dropout=0.0, downsample=True, downsample_use_conv=True):
+        super().__init__(in_channels, out_channels, n_blocks=n_blocks, n_heads=n_heads, n_dim_head=n_dim_head,
+                         norm_groups=norm_groups, activation=activation, dropout=dropout, downsample=downsample,
+                         downsample_use_conv=downsample_use_conv)
+
+    def forward(self, x: torch.Tensor):
+        return self._run(x, None)[0]
+
+
+class UNetUpBlock(_UpStage):
+    def __init__(self, in_channels, out_channels, next_out_channels, n_blocks=2, norm_groups=32,
+                 activation="swish", embedding_dim=None, embedding_mixing="addition", dropout=0.0, upsample=True,
+                 upsample_use_conv=True):
+        super().__init__(in_channels, out_channels, next_out_channels, n_blocks=n_blocks, norm_groups=norm_groups,
+                         activation=activation, embedding_dim=embedding_dim, embedding_mixing=embedding_mixing,
+                         dropout=dropout, upsample=upsample, upsample_use_conv=upsample_use_conv)
+
+    def forward(self, x: torch.Tensor, skips: Tuple[torch.Tensor], embedding: Optional[torch.Tensor] = None):
+        return self._run(x, skips, embedding)
+
+
+class UNetAttnUpBlock(_UpStage):
+    _with_attention = True
+
+    def forward(self, x: torch.Tensor, skips: Tuple[torch.Tensor], embedding: Optional[torch.Tensor] = None):
+        return self._run(x, skips, embedding)
+
+
+class DecoderUpBlock(_UpStage):
+    _with_embedding = False
+
+    def __init__(self, in_channels, out_channels, n_blocks=2, norm_groups=32, activation="swish", dropout=0.0,
+                 upsample=True, upsample_use_conv=True):
+        super().__init__(in_channels, out_channels, None, n_blocks=n_blocks, norm_groups=norm_groups,
+                         activation=activation, dropout=dropout, upsample=upsample,
+                         upsample_use_conv=upsample_use_conv)
+
+    def forward(self, x: torch.Tensor):
+        return self._run(x, None, None)
+
+
+class DecoderAttnUpBlock(_UpStage):
+    _with_attention = True
+    _with_embedding = False
+
+    def __init__(self, in_channels, out_channels, n_blocks=2, n_heads=None, n_dim_head=None, norm_groups=32,
+                 activation="swish", dropout=0.0, upsample=True, upsample_use_conv=True):
+        super().__init__(in_channels, out_channels, None, n_blocks=n_blocks, n_heads=n_heads,
+                         n_dim_head=n_dim_head, norm_groups=norm_groups, activation=activation, dropout=dropout,
+                         upsample=upsample, upsample_use_conv=upsample_use_conv)
+
+    def forward(self, x: torch.Tensor):
+        return self._run(x, None, None)
+
+
+class MidBlock(nn.Module):
+    """block0, then n_blocks x ([attention] -> block) (reference: modeling/blocks.py:368-419)."""
+
+    def __init__(self, channels: int, n_blocks: int = 1, n_heads: Optional[int] = None,
+                 n_dim_head: Optional[int] = None, norm_groups: int = 32, activation: str = "swish",
+                 embedding_dim: Optional[int] = None, embedding_mixing: str = "addition",
+                 add_attention: bool = True, dropout: float = 0.0):
+        super().__init__()
+
+        def conv_block():
+            return ConvBlock(channels, out_channels=channels, norm_groups=norm_groups, activation=activation,
+                             embedding_dim=embedding_dim, embedding_mixing=embedding_mixing, dropout=dropout)
+
+        blocks, attentions = [conv_block()], []
+        for _ in range(n_blocks):
+            blocks.append(conv_block())
+            attentions.append(Attention2D(channels, n_heads=n_heads, n_dim_head=n_dim_head,
+                                          norm_groups=norm_groups, dropout=dropout) if add_attention else None)
+        self.blocks = nn.ModuleList(blocks)
+        self.attentions = nn.ModuleList(attentions)
+
+    def forward(self, x: torch.Tensor, embedding: Optional[torch.Tensor] = None):
+        x = self.blocks[0](x, embedding=embedding)
+        for block, attention in zip(self.blocks[1:], self.attentions):
+            if attention is not None:
+                x = attention(x)
+            x = block(x, embedding=embedding)
+        return x
+
+
+_DOWN_TYPES = {
+    "UNetDownBlock": (UNetDownBlock, False, True),
+    "UNetAttnDownBlock": (UNetAttnDownBlock, True, True),
+    "EncoderDownBlock": (EncoderDownBlock, False, False),
+    "EncoderAttnDownBlock": (EncoderAttnDownBlock, True, False),
+}
+_UP_TYPES = {
+    "UNetUpBlock": (UNetUpBlock, False, True),
+    "UNetAttnUpBlock": (UNetAttnUpBlock, True, True),
+    "DecoderUpBlock": (DecoderUpBlock, False, False),
+    "DecoderAttnUpBlock": (DecoderAttnUpBlock, True, False),
+}
+
+
+def get_down_block(block_type: str, in_channels: int, out_channels: int, n_blocks: int = 2,
+                   n_heads: Optional[int] = None, n_dim_head: Optional[int] = None, norm_groups: int = 32,
+                   activation: str = "swish", embedding_dim: Optional[int] = None,
+                   embedding_mixing: str = "addition", dropout: float = 0.0, downsample: bool = True,
+                   downsample_use_conv: bool = True):
+    if block_type not in _DOWN_TYPES:
+        raise ValueError(f'unknown down block type "{block_type}"')
+    cls, attn, emb = _DOWN_TYPES[block_type]
+    kw = dict(in_channels=in_channels, out_channels=out_channels, n_blocks=n_blocks, norm_groups=norm_groups,
+              activation=activation, dropout=dropout, downsample=downsample,
+              downsample_use_conv=downsample_use_conv)
+    if attn:
+        kw.update(n_heads=n_heads, n_dim_head=n_dim_head)
+    if emb:
+        kw.update(embedding_dim=embedding_dim, embedding_mixing=embedding_mixing)
+    return cls(**kw)
+
+
+def get_up_block(block_type: str, in_channels: int, out_channels: int, next_out_channels: Optional[int] = None,
+                 n_blocks: int = 2, n_heads: Optional[int] = None, n_dim_head: Optional[int] = None,
+                 norm_groups: int = 32, activation: str = "swish", embedding_dim: Optional[int] = None,
+                 embedding_mixing: str = "addition", dropout: float = 0.0, upsample: bool = True,
+                 upsample_use_conv: bool = True):
+    if block_type not in _UP_TYPES:
+        raise ValueError(f'unknown up block type "{block_type}"')
+    cls, attn, emb = _UP_TYPES[block_type]
+    kw = dict(in_channels=in_channels, out_channels=out_channels, n_blocks=n_blocks, norm_groups=norm_groups,
+              activation=activation, dropout=dropout, upsample=upsample, upsample_use_conv=upsample_use_conv)
+    if attn:
+        kw.update(n_heads=n_heads, n_dim_head=n_dim_head)
+    if emb:
+        kw.update(next_out_channels=next_out_channels, embedding_dim=embedding_dim,
+                  embedding_mixing=embedding_mixing)
+    return cls(**kw)

@@ -1,0 +1,125 @@
+"""Class-conditional UNet denoiser (reference: modeling/unet.py:13-166).
+
+Constructor arguments, sub-module names and state-dict keys follow the reference; the image enters and leaves
+as NCHW fp32, everything in between is pixel-major bf16 handled by libdm_hip kernels.
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from dm_hip import ops
+from modeling.activation import get_activation, is_silu
+from modeling.blocks import MidBlock, get_down_block, get_up_block
+from modeling.embeddings import MLPEmbedding, PeriodicEncoding
+from modeling.layers import GroupNorm
+from modeling.predictor import GuidedPredictor
+
+
+class _EdgeConv(nn.Conv2d):
+    """3x3 'same' conv with 1-4 channels on one side; parameters in the stock layout, kernels on the VALU."""
+
+    def __init__(self, in_channels, out_channels, image_side: str):
+        super().__init__(in_channels, out_channels, kernel_size=3, padding="same")
+        self._image_side = image_side
+
+    def forward(self, x):
+        if self._image_side == "in":
+            return ops.in_conv(x, self.weight, self.bias)
+        return ops.out_conv(x, self.weight, self.bias)
+
+
+class UNet(nn.Module, GuidedPredictor):
+    def __init__(
+            self,
+            in_channels: int = 3,
+            out_channels: int = 3,
+            down_block_types: Tuple[str, ...] = ("UNetDownBlock",),
+            up_block_types: Tuple[str, ...] = ("UNetUpBlock",),
+            block_out_channels: Tuple[int, ...] = (64,),
+            n_blocks_per_layer: int = 2,
+            n_attention_heads: Optional[int] = None,
+            n_dim_attention_head: Optional[int] = None,
+            mid_attention: bool = True,
+            norm_groups: int = 32,
+            activation: str = "silu",
+            time_encoding_dim: int = 64,
+            embedding_dim: int = 64,
+            embedding_mixing: str = "addition",
+            n_class_embeddings: Optional[int] = None,
+            dropout: float = 0.0,
+            downsample_use_conv: bool = True,
+            upsample_use_conv: bool = True,
+    ):
+        super().__init__()
+        assert len(down_block_types) == len(up_block_types) == len(block_out_channels)
+        n_levels = len(block_out_channels)
+        widths = list(block_out_channels)
+
+        self.in_conv = _EdgeConv(in_channels, widths[0], image_side="in")
+        self.time_embedding = nn.Sequential(
+            PeriodicEncoding(time_encoding_dim),
+            MLPEmbedding(time_encoding_dim, embedding_dim),
+        )
+        if n_class_embeddings is not None:
+            self.class_embedding = nn.Embedding(n_class_embeddings + 1, embedding_dim, padding_idx=n_class_embeddings)
+            self.register_buffer("uncond_class", torch.tensor(n_class_embeddings))
+            self._uncond_idx = int(n_class_embeddings)
+        else:
+            self.class_embedding = None
+
+        shared = dict(n_heads=n_attention_heads, n_dim_head=n_dim_attention_head, norm_groups=norm_groups,
+                      activation=activation, embedding_dim=embedding_dim, embedding_mixing=embedding_mixing,
+                      dropout=dropout)
+
+        down, prev = [], widths[0]
+        for level, kind in enumerate(down_block_types):
+            down.append(get_down_block(kind, in_channels=prev, out_channels=widths[level],
+                                       n_blocks=n_blocks_per_layer, downsample=level < n_levels - 1,
+                                       downsample_use_conv=downsample_use_conv, **shared))
+            prev = widths[level]
+
+        up, up_widths = [], widths[::-1] + [widths[0]]
+        for level, kind in enumerate(up_block_types):
+            up.append(get_up_block(kind, in_channels=prev, out_channels=up_widths[level],
+                                   next_out_channels=up_widths[level + 1], n_blocks=n_blocks_per_layer + 1,
+                                   upsample=level < n_levels - 1, upsample_use_conv=upsample_use_conv, **shared))
+            prev = up_widths[level]
+
+        self.down = nn.ModuleList(down)
+        self.mid = MidBlock(channels=widths[-1], add_attention=mid_attention, **shared)
+        self.up = nn.ModuleList(up)
+
+        self.out_norm = GroupNorm(norm_groups, widths[0])
+        self.out_act = get_activation(activation)
+        self.out_conv = _EdgeConv(widths[0], out_channels, image_side="out")
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, cls: Optional[torch.Tensor] = None,
+                uncond_mask: Optional[torch.Tensor] = None):
+        embedding = self.time_embedding(t)
+        if self.class_embedding is not None:
+            # masked / missing labels map to the padding row, which is zero and never receives gradient
+            embedding = ops.class_embed_add(embedding, self.class_embedding.weight, cls,
+                                            uncond_mask if cls is not None else None, self._uncond_idx)
+
+        h = self.in_conv(x)
+        skips = (h,)
+        for stage in self.down:
+            h, stage_skips = stage(h, embedding=embedding)
+            skips += stage_skips
+
+        h = self.mid(h, embedding=embedding)
+
+        for stage in self.up:
+            n = len(stage.blocks)
+            stage_skips, skips = skips[-n:], skips[:-n]
+            h = stage(h, stage_skips, embedding=embedding)
+
+        if is_silu(self.out_act):
+            h = self.out_norm(h, act=True)
+        else:
+            h = self.out_act(self.out_norm(h, act=False))
+        return self.out_conv(h)
+
+    def pred_conditional(self, z, t, cond=None, uncond_mask=None):
+        return self.forward(z, t, cls=cond, uncond_mask=uncond_mask)

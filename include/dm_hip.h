@@ -1,0 +1,207 @@
+/* C ABI of libdm_hip.so: hand-written gfx950 (MI355X) kernels for the UNet denoiser training step and
+ * sampling loop of Thxios/diffusion-models.
+ *
+ * The reference has no FFI of its own: every operator below replaces a stock PyTorch call site inside the
+ * reference's Python modules; each declaration cites the call site (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller, 16-byte aligned unless noted; nothing is allocated,
+ *     freed or synchronised inside; every kernel is launched on `stream` (a hipStream_t) and returns at once
+ *   - activations are "pixel-major" (NHWC): a[m][c], m = (b*H + h)*W + w, stored as bf16
+ *   - parameters, statistics, embeddings, losses and gradients of parameters are fp32
+ *   - return value: 0 (DM_OK) or a dm_status code; dm_last_error() returns the message of the calling thread's
+ *     last failure
+ */
+#ifndef DM_HIP_H
+#define DM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum dm_status {
+  DM_OK = 0,
+  DM_ERR_ARG = 1,         /* null / misaligned / inconsistent argument */
+  DM_ERR_SHAPE = 2,       /* shape the kernels do not cover (e.g. channels not a multiple of 64) */
+  DM_ERR_LAUNCH = 3,      /* the HIP runtime refused the launch */
+  DM_ERR_UNSUPPORTED = 4
+} dm_status;
+
+const char* dm_last_error(void);
+int dm_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on bf16 MFMA.
+ * Replaces nn.Conv2d in modeling/blocks.py:26,28 (3x3 'same'), :45 (1x1 res_proj), :89 (3x3 stride 2 pad 1),
+ * :110 (3x3 after F.interpolate, :116), the nn.Linear projections of modeling/attention.py:59-60 (as 1x1
+ * convs over B*L "pixels"), torch.cat of modeling/blocks.py:290 (two-source channel axis), and their autograd
+ * gradients.
+ *
+ * x1|x2 : bf16 [B][Hs][Ws][C1] and optionally [B][Hs][Ws][C2]; the conv sees channels (x1 | x2)
+ * w      : bf16 [Cout][KH*KW][C1+C2]
+ * ups=1  : the conv input is the nearest-neighbour x2 upsampling of the source (never materialised)
+ * transposed=1 : data-gradient gather. Then x1 is dy [B][Hs][Ws][C1] of a forward conv with this
+ *          KH/KW/stride/pad whose INPUT was [B][Ho][Wo][Cout]; w is [Cin_fwd][KH*KW][Cout_fwd] (channel roles
+ *          swapped, taps NOT flipped); the result is dx.
+ */
+typedef struct dm_conv_desc {
+  int B, Hs, Ws;
+  int C1, C2;
+  int Cout;
+  int KH, KW, stride, pad;
+  int ups;
+  int transposed;
+  int Ho, Wo;
+} dm_conv_desc;
+
+/* y[m][n] = conv(x)[m][n] + bias[n] + res[m][n]; bias (fp32 [Cout]) and res (bf16 [M][Cout]) may be null */
+int dm_conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                    const void* res, void* y, void* stream);
+
+/* dw[n][tap][c] += sum_m dy[m][n] * X(m,tap)[c]; dw fp32 [Cout][KH*KW][C1+C2], ACCUMULATES (atomics) */
+int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, void* stream);
+
+/* fp32 parameter [Cout][Cin][KH][KW] with arbitrary element strides -> bf16 [Cout][T][Cin] (w_fwd) and
+ * bf16 [Cin][T][Cout] (w_dgrad); either output may be null */
+int dm_pack_conv_weight(const float* w, long s_co, long s_ci, long s_kh, long s_kw, int Cout, int Cin, int KH,
+                        int KW, void* w_fwd, void* w_dgrad, void* stream);
+
+/* out[c] += sum_m x[m][c]  (bias gradients; x bf16 [M][C], out fp32) */
+int dm_colsum_bf16(const void* x, float* out, long M, int C, void* stream);
+/* out[c] += sum_r x[r][c]  (x fp32 [R][C]) */
+int dm_colsum_f32(const float* x, float* out, int R, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Edge convolutions (few channels on one side; HBM-bound, VALU).
+ * in:  modeling/unet.py:44,147  (in_conv,  NCHW fp32 image -> NHWC bf16 features)
+ * out: modeling/unet.py:126,162 (out_conv, NHWC bf16 features -> NCHW fp32 image)
+ * Weights stay in the parameter layout [Cout][Cin][3][3] fp32 (contiguous).
+ */
+int dm_in_conv_fwd(const float* x, const float* w, const float* bias, void* y, int B, int Cs, int H, int W, int Cb,
+                   void* stream);
+int dm_out_conv_fwd(const void* h, const float* w, const float* bias, float* y, int B, int Cs, int H, int W, int Cb,
+                    void* stream);
+/* dh[m][cb] = sum_{co,tap} dy[b][co][...] * w[co][cb][tap]   (gradient w.r.t. out_conv's input) */
+int dm_out_conv_dgrad(const float* dy, const float* w, void* dh, int B, int Cs, int H, int W, int Cb, void* stream);
+/* Gradients of a 3x3 'same' edge conv's weight (and bias): `small` is the NCHW fp32 side with Cs channels, `big`
+ * the NHWC bf16 side with Cb channels.
+ *   big_is_output=1 (in_conv):  dw[cb][cs][kh][kw] += sum big[m][cb] * small[b][cs][h+kh-1][w+kw-1]; dbias[cb] += sum big
+ *   big_is_output=0 (out_conv): dw[cs][cb][kh][kw] += sum small[b][cs][h][w] * big[(h+kh-1, w+kw-1)][cb]; dbias[cs] += sum small
+ */
+int dm_edge_conv_wgrad(const float* small, const void* big, float* dw, float* dbias, int B, int Cs, int H, int W,
+                       int Cb, int big_is_output, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * GroupNorm (+ per-sample scale/shift or pre-add) (+ SiLU), fused; channel axis may be two sources.
+ * Replaces nn.GroupNorm + nn.SiLU in modeling/blocks.py:50-51, :59-70, modeling/unet.py:160-161,
+ * modeling/attention.py:67, and torch.cat of modeling/blocks.py:290.
+ *   xin = (x1 | x2)[b][p][c] + pre_add[b][c]
+ *   v   = gamma[c] * (xin - mean[b][g]) * rstd[b][g] + beta[c]
+ *   u   = has_ss ? (1 + ss[b][c]) * v + ss[b][C + c] : v
+ *   y   = act ? silu(u) : u                                   (bf16 [B][HW][C])
+ */
+typedef struct dm_gn_desc {
+  int B, HW, C1, C2, G;
+  float eps;
+  int act;     /* 0 none, 1 SiLU */
+  int has_ss;  /* scale_shift fp32 [B][2C] present */
+  int has_pre; /* pre_add fp32 [B][C] present */
+} dm_gn_desc;
+
+int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma, const float* beta,
+                         const float* scale_shift, const float* pre_add, void* y, float* mean, float* rstd,
+                         void* stream);
+/* dx1|dx2 bf16 (= GN backward + dextra, dextra optional bf16 [B][HW][C]); dgamma_part/dbeta_part fp32 [B][C]
+ * (per-sample partials, to be column-summed); dscale_shift fp32 [B][2C] and dpre_add fp32 [B][C] when present */
+int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma, const float* beta,
+                         const float* scale_shift, const float* pre_add, const float* mean, const float* rstd,
+                         const void* dy, const void* dextra, void* dx1, void* dx2, float* dgamma_part,
+                         float* dbeta_part, float* dscale_shift, float* dpre_add, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Spatial self-attention core. Replaces F.scaled_dot_product_attention and the view/permute/contiguous
+ * shuffles of modeling/attention.py:71-79.
+ * qkv bf16 [B][L][3][H][D] (the qkv_proj output as is), out bf16 [B][L][H][D], lse fp32 [B][H][L]; D in {8,16,32,64}
+ */
+int dm_attention_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int D, float scale, void* stream);
+int dm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int L,
+                     int H, int D, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Embedding path (fp32, tiny): modeling/embeddings.py:24-27 (sinusoidal encoding), :43-47 (MLP),
+ * modeling/blocks.py:56-57 (emb_proj of SiLU(embedding)), modeling/unet.py:138-145 (class embedding add).
+ */
+int dm_timestep_embed(const int64_t* t, const float* freq, float* out, int B, int half, void* stream);
+/* y[m][n] = sum_k f(x[m][k]) * w[n][k] + bias[n], f = SiLU if act_in else identity */
+int dm_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act_in,
+                  void* stream);
+/* dx[m][k] = f'(x[m][k]) * sum_n dy[m][n] w[n][k]  (dx may be null);  dw[n][k] += sum_m dy[m][n] f(x[m][k]);
+ * dbias[n] += sum_m dy[m][n]  (dw/dbias may be null) */
+int dm_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias, int M, int K,
+                  int N, int act_in, void* stream);
+/* emb[b][:] += table[idx(b)][:], idx(b) = (cls == null || mask[b] != 0) ? uncond_idx : cls[b] */
+int dm_class_embed_add(float* emb, const float* table, const int64_t* cls, const float* mask, int uncond_idx, int B,
+                       int E, void* stream);
+/* dtable[idx(b)][:] += demb[b][:] for idx(b) != uncond_idx (the padding row never receives gradient) */
+int dm_class_embed_bwd(const float* demb, float* dtable, const int64_t* cls, const float* mask, int uncond_idx, int B,
+                       int E, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Resampling without conv (modeling/blocks.py:92 AvgPool2d, :116 F.interpolate nearest) and the 2x2 gather of
+ * the fused-upsample conv's data gradient. All bf16 NHWC.
+ */
+int dm_upsample2x_fwd(const void* x, void* y, int B, int H, int W, int C, void* stream);  /* y [B][2H][2W][C] */
+int dm_upsample2x_bwd(const void* dy, void* dx, int B, int H, int W, int C, void* stream); /* dx[h][w] = sum of 4 */
+int dm_avgpool2x_fwd(const void* x, void* y, int B, int H, int W, int C, void* stream);   /* y [B][H/2][W/2][C] */
+int dm_avgpool2x_bwd(const void* dy, void* dx, int B, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Diffusion process (all fp32, NCHW or any layout with the sample index slowest; n = elements per sample).
+ * mode 0 (variance preserving, diffusion/scheduler.py:75-83): a = (float)sqrt(tab64[t]), s = (float)sqrt(1 - tab64[t])
+ * mode 1 (rectified flow,      diffusion/scheduler.py:149-153): s = tab32[t], a = 1 - s
+ *   x_t = a * x + s * eps
+ */
+int dm_diffuse(const float* x, const float* eps, const int64_t* t, const double* tab64, const float* tab32,
+               float* x_t, int B, long n, int mode, void* stream);
+/* loss = mean((pred - target)^2), target = eps (mode 0, scheduler.py:72) or x - eps (mode 1, scheduler.py:146).
+ * partials: fp32 scratch of dm_mse_partials() elements; loss: one fp32 */
+int dm_mse_partials(void);
+int dm_mse_loss_fwd(const float* pred, const float* x, const float* eps, float* partials, float* loss, long total,
+                    int mode, void* stream);
+/* dpred = gout[0] * 2 (pred - target) / total */
+int dm_mse_loss_bwd(const float* pred, const float* x, const float* eps, const float* gout, float* dpred, long total,
+                    int mode, void* stream);
+
+/* One sampler update, in place on z (diffusion/sampler.py). Scalars are the per-step table entries.
+ * mode 0 DDPM  (:80-84):    z = c0 * (z - c1 * pred);  if noise: z += c2 * noise
+ * mode 1 DDIM  (:116-130):  x0 = (z - c1 * pred) / c0; if clip: clamp(x0,-1,1); z = last ? x0 : c2 * x0 + c3 * pred
+ * mode 2 Euler (:157-162):  z = z - c0 * pred
+ */
+int dm_sampler_step(float* z, const float* pred, const float* noise, float c0, float c1, float c2, float c3, int mode,
+                    int clip, int last, long total, void* stream);
+/* out = u + s * (c - u)   (modeling/predictor.py:29) */
+int dm_cfg_combine(const float* pred_uncond, const float* pred_cond, float* out, float s, long total, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Optimizer tail on flat fp32 arenas (train.py:441-450: clip_grad_norm_, AdamW.step, EMAModel.step).
+ */
+int dm_sumsq_partials(void);
+/* norm_out[0] = sqrt(sum g^2); partials: fp32 scratch of dm_sumsq_partials() elements */
+int dm_grad_norm(const float* g, long n, float* partials, float* norm_out, void* stream);
+/* clip = min(1, max_norm / (norm[0] + 1e-6)) applied to g on the fly (max_norm <= 0: no clipping);
+ * AdamW with decoupled weight decay and bias corrections bc1 = 1 - b1^step, bc2 = 1 - b2^step; then
+ * ema -= (1 - ema_decay) * (ema - p) when ema != null; w_bf16 (nullable) receives the bf16 copy of p */
+int dm_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* w_bf16, const float* norm,
+                      float max_norm, long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                      float ema_decay, const float* hyper, void* stream);
+/* Device-side step bookkeeping for graph replay: step[0] += 1; hyper = {lr, 1 - b1^step, 1 - b2^step, ema_decay}
+ * with the warm-up EMA rule decay = min(1 - (1 + (step-1)/inv_gamma)^-power, max_decay) (0 on the first step).
+ * When `hyper` (device, 4 floats) is passed to dm_adamw_ema_step it overrides lr, bc1, bc2 and ema_decay. */
+int dm_optimizer_tick(long long* step, float* hyper, float lr, float b1, float b2, float ema_inv_gamma, float ema_power,
+                      float ema_max_decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,112 @@
+"""Helpers shared by the parity tests, smoke() and bench.py: golden loading, deterministic weights, error
+metrics, and construction of (oracle state dict, HIP model) pairs."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+PKG = os.path.join(ROOT, "diffusion-models_amd")
+for p in (ROOT, PKG, GOLDEN):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from detweights import det_state_dict  # noqa: E402
+
+TINY_CFG = dict(
+    in_channels=3, out_channels=3,
+    down_block_types=["UNetDownBlock", "UNetDownBlock"], up_block_types=["UNetUpBlock", "UNetUpBlock"],
+    block_out_channels=[64, 128], n_blocks_per_layer=1, mid_attention=True, n_dim_attention_head=8,
+    norm_groups=32, activation="silu", time_encoding_dim=64, embedding_dim=64,
+    embedding_mixing="scale_shift", n_class_embeddings=10, dropout=0.0,
+    downsample_use_conv=True, upsample_use_conv=True,
+)
+TINY_ATTN_CFG = dict(TINY_CFG, down_block_types=["UNetDownBlock", "UNetAttnDownBlock"],
+                     up_block_types=["UNetAttnUpBlock", "UNetUpBlock"], embedding_mixing="addition")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def load_cfg(name):
+    with open(os.path.join(GOLDEN, "arg_json", name + ".json")) as f:
+        return json.load(f)
+
+
+def contract():
+    with open(os.path.join(GOLDEN, "state_dict_contract.json")) as f:
+        return json.load(f)
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dtype) if dtype is not None else t
+
+
+def det_sd_for(module, seed):
+    """Deterministic state dict (torch CPU tensors) for a module's state-dict layout; buffers keep their value."""
+    sd = module.state_dict()
+    vals = det_state_dict([(k, v.shape) for k, v in sd.items()], seed)
+    return {k: (T(vals[k]) if vals[k] is not None else v.detach().cpu().clone()) for k, v in sd.items()}
+
+
+def rel_err(a, b):
+    """||a - b|| / ||b|| in fp64."""
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def max_abs(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+def smoke_check():
+    """One tiny UNet training step on cuda:0 through the HIP kernels, checked against the CPU oracle."""
+    from modeling import get_model
+    from diffusion.scheduler import get_scheduler
+    from oracle import unet_oracle as O
+
+    assert torch.cuda.is_available(), "smoke() needs a GPU"
+    dev = torch.device("cuda:0")
+    model = get_model("unet", **TINY_CFG)
+    sd = det_sd_for(model, 900)
+    model.load_state_dict(sd)
+    model.to(dev).train()
+    rs = np.random.RandomState(901)
+    B = 4
+    x = T(rs.uniform(-1, 1, size=(B, 3, 16, 16)).astype(np.float32))
+    cls = T(rs.randint(0, 10, size=(B,)).astype(np.int64))
+    mask = T((rs.uniform(size=(B,)) < 0.3).astype(np.float32))
+    eps = T(rs.standard_normal((B, 3, 16, 16)).astype(np.float32))
+    t = T(rs.randint(0, 1000, size=(B,)).astype(np.int64))
+    sched = get_scheduler("beta", schedule="cosine")
+
+    from dm_hip import ops
+    x_t = sched.diffuse(x.to(dev), t.to(dev), eps.to(dev))
+    pred = model(x_t, t.to(dev), cls=cls.to(dev), uncond_mask=mask.to(dev))
+    loss = ops.mse_loss(pred, eps.to(dev), mode=0)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    osd = {k: v.clone() for k, v in sd.items()}
+    names = O.param_names(osd)
+    params = {k: osd[k].requires_grad_(True) for k in names}
+    live = dict(osd)
+    live.update(params)
+    ol = O.loss_vp(lambda a, b, **kw: O.unet_forward(live, TINY_CFG, a, b, **kw), x, t, eps,
+                   O.alpha_sq_from_beta(O.beta_cosine()), cls=cls, uncond_mask=mask)
+    og = torch.autograd.grad(ol, [params[k] for k in names], allow_unused=True)
+    e_loss = abs(float(loss) - float(ol)) / abs(float(ol))
+    worst = 0.0
+    got = dict(model.named_parameters())
+    for k, g in zip(names, og):
+        if g is None or float(g.norm()) < 1e-8:
+            continue
+        worst = max(worst, rel_err(got[k].grad, g))
+    print(f"smoke: loss hip={float(loss):.6f} oracle={float(ol):.6f} rel={e_loss:.2e}; worst grad rel-err={worst:.3e}")
+    assert e_loss < 2e-2, "loss mismatch against the CPU oracle"
+    assert worst < 8e-2, "gradient mismatch against the CPU oracle"

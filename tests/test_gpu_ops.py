@@ -1,0 +1,330 @@
+"""GPU: each libdm_hip operator (called through the C ABI via dm_hip.ops) against a plain PyTorch fp32 CPU
+reference of the same op on the same seeded inputs.
+
+Tolerances (relative L2 error against the fp32 reference, written per test): activations are stored in bf16
+(8 significant bits, unit round-off 2^-9 = 2e-3), products accumulate in fp32. fp32 kernels are held to ~1e-5;
+the diffusion elementwise kernels are bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.parity import T, golden, max_abs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+BF16_FWD = 6e-3     # one bf16 rounding of inputs + one of the output
+BF16_BWD = 1.2e-2   # gradients pass through one more bf16 tensor
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def q(x):
+    """Round to bf16 and back: the reference then sees exactly the values the kernels see."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def rnd(rs, *shape, scale=1.0):
+    return T((rs.standard_normal(shape) * scale).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, C1, C2, Cout, H, W, k, stride, ups
+    (2, 64, 0, 64, 8, 8, 3, 1, 0),
+    (3, 128, 0, 128, 16, 16, 3, 1, 0),      # M = 768: six full tiles
+    (2, 64, 0, 192, 7, 7, 3, 1, 0),         # ragged M (98), Cout not a multiple of 128
+    (2, 128, 64, 128, 8, 8, 1, 1, 0),       # two-source 1x1 (res_proj over a skip concat)
+    (2, 64, 128, 64, 5, 9, 3, 1, 0),        # two-source 3x3, non-square
+    (2, 64, 0, 64, 16, 16, 3, 2, 0),        # stride 2 pad 1
+    (2, 64, 0, 128, 7, 7, 3, 2, 0),         # stride 2 on an odd size (7 -> 4)
+    (2, 64, 0, 128, 4, 4, 3, 1, 1),         # fused nearest x2 upsample
+    (1, 256, 0, 512, 8, 8, 3, 1, 0),        # deep reduction (K = 2304)
+    (5, 64, 0, 64, 1, 1, 1, 1, 0),          # degenerate: a linear layer
+]
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,H,W,k,stride,ups", CONV_CASES)
+def test_conv2d_fwd_bwd(B, C1, C2, Cout, H, W, k, stride, ups):
+    from dm_hip import ops
+    rs = np.random.RandomState(hash((B, C1, C2, Cout, H, W, k, stride, ups)) % (2 ** 31))
+    pad = (k - 1) // 2
+    x1 = q(rnd(rs, B, C1, H, W))
+    x2 = q(rnd(rs, B, C2, H, W)) if C2 else None
+    w = rnd(rs, Cout, C1 + C2, k, k, scale=(1.0 / np.sqrt((C1 + C2) * k * k)))
+    b = rnd(rs, Cout, scale=0.1)
+    # reference (fp32, CPU) with bf16-rounded weights, as the kernel packs them
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    xin = xin.clone().requires_grad_(True)
+    wq = q(w).clone().requires_grad_(True)
+    bb = b.clone().requires_grad_(True)
+    xu = F.interpolate(xin, scale_factor=2, mode="nearest") if ups else xin
+    y_ref = F.conv2d(xu, wq, bb, stride=stride, padding=pad)
+    res = q(rnd(rs, *y_ref.shape))
+    resr = res.clone().requires_grad_(True)
+    y_ref = y_ref + resr
+    gy = q(rnd(rs, *y_ref.shape))
+    y_ref.backward(gy)
+
+    d = dev()
+    x1d = x1.to(d).requires_grad_(True)
+    x2d = x2.to(d).requires_grad_(True) if x2 is not None else None
+    wd = w.to(d).requires_grad_(True)
+    bd = b.to(d).requires_grad_(True)
+    resd = res.to(d).requires_grad_(True)
+    pack = ops.WeightPack()
+    y = ops.conv2d(x1d, wd, bd, pack, x2=x2d, res=resd, stride=stride, pad=pad, ups=ups)
+    assert tuple(y.shape) == tuple(y_ref.shape) and y.dtype == torch.bfloat16
+    assert rel_err(y.float(), y_ref) < BF16_FWD
+    y.backward(gy.to(d))
+    gx = x1d.grad.float() if x2d is None else torch.cat([x1d.grad.float(), x2d.grad.float()], 1)
+    assert rel_err(gx, xin.grad) < BF16_FWD
+    assert rel_err(wd.grad, wq.grad) < 2e-3           # fp32 accumulation of exact bf16 products
+    assert rel_err(bd.grad, bb.grad) < 1e-4
+    assert rel_err(resd.grad.float(), resr.grad) < 1e-6
+
+
+GN_CASES = [
+    # B, C1, C2, H, W, act, ss, pre
+    (2, 64, 0, 8, 8, True, False, False),
+    (2, 128, 0, 4, 4, True, True, False),
+    (3, 128, 64, 4, 4, True, False, False),     # group size 6: vectors straddle groups, groups straddle sources
+    (2, 256, 128, 8, 8, True, True, False),     # group size 12
+    (2, 64, 0, 7, 7, False, False, False),      # plain GroupNorm (attention)
+    (2, 128, 0, 5, 3, True, False, True),       # 'addition' embedding mixing
+    (2, 512, 512, 2, 2, True, True, False),     # widest concat of the CIFAR model
+]
+
+
+@pytest.mark.parametrize("B,C1,C2,H,W,act,ss,pre", GN_CASES)
+def test_groupnorm_act_fwd_bwd(B, C1, C2, H, W, act, ss, pre):
+    from dm_hip import ops
+    rs = np.random.RandomState(B * 1000 + C1 + C2 + H)
+    C, G = C1 + C2, 32
+    x1 = q(rnd(rs, B, C1, H, W) + 0.5)
+    x2 = q(rnd(rs, B, C2, H, W, scale=2.0)) if C2 else None
+    gamma, beta = 1 + 0.2 * rnd(rs, C), 0.2 * rnd(rs, C)
+    sst = 0.5 * rnd(rs, B, 2 * C) if ss else None
+    pret = rnd(rs, B, C) if pre else None
+
+    leaves = [t.clone().requires_grad_(True) for t in (x1, gamma, beta)]
+    x1r, gr, br = leaves
+    x2r = x2.clone().requires_grad_(True) if x2 is not None else None
+    ssr = sst.clone().requires_grad_(True) if ss else None
+    prer = pret.clone().requires_grad_(True) if pre else None
+    xin = x1r if x2r is None else torch.cat([x1r, x2r], 1)
+    if pre:
+        xin = xin + prer[:, :, None, None]
+    v = F.group_norm(xin, G, gr, br, eps=1e-5)
+    if ss:
+        sc, sh = torch.chunk(ssr[:, :, None, None], 2, dim=1)
+        v = (1 + sc) * v + sh
+    y_ref = F.silu(v) if act else v
+    gy = q(rnd(rs, *y_ref.shape))
+    y_ref.backward(gy)
+
+    d = dev()
+    mk = lambda t: t.to(d).requires_grad_(True) if t is not None else None  # noqa: E731
+    x1d, x2d, gd, bd, ssd, pred_ = mk(x1), mk(x2), mk(gamma), mk(beta), mk(sst), mk(pret)
+    y = ops.group_norm_act(x1d, gd, bd, G, 1e-5, act, x2=x2d, scale_shift=ssd, pre_add=pred_)
+    assert rel_err(y.float(), y_ref) < BF16_FWD
+    y.backward(gy.to(d))
+    assert rel_err(x1d.grad.float(), x1r.grad) < BF16_FWD
+    if x2d is not None:
+        assert rel_err(x2d.grad.float(), x2r.grad) < BF16_FWD
+    assert rel_err(gd.grad, gr.grad) < 1e-4 and rel_err(bd.grad, br.grad) < 1e-4
+    if ss:
+        assert rel_err(ssd.grad, ssr.grad) < 1e-4
+    if pre:
+        assert rel_err(pred_.grad, prer.grad) < 2e-4
+
+
+@pytest.mark.parametrize("B,L,H,D", [(2, 64, 8, 8), (2, 49, 16, 8), (1, 256, 4, 16), (3, 16, 2, 32), (1, 100, 1, 64)])
+def test_attention_fwd_bwd(B, L, H, D):
+    from dm_hip import ops
+    rs = np.random.RandomState(B + L + H + D)
+    qkv = q(rnd(rs, B, L, 3 * H * D))
+    qr = qkv.clone().requires_grad_(True)
+    t = qr.view(B, L, 3, H, D).permute(2, 0, 3, 1, 4)
+    o_ref = F.scaled_dot_product_attention(t[0], t[1], t[2]).transpose(1, 2).reshape(B, L, H * D)
+    go = q(rnd(rs, B, L, H * D))
+    o_ref.backward(go)
+    qd = qkv.to(dev()).to(torch.bfloat16).requires_grad_(True)
+    o = ops.attention(qd, H, D)
+    assert rel_err(o.float(), o_ref) < BF16_FWD
+    o.backward(go.to(dev()).to(torch.bfloat16))
+    assert rel_err(qd.grad.float(), qr.grad) < BF16_BWD
+
+
+@pytest.mark.parametrize("M,K,N,act", [(8, 64, 128, False), (128, 128, 1024, True), (5, 64, 64, True), (33, 128, 192, False)])
+def test_linear_fwd_bwd(M, K, N, act):
+    from dm_hip import ops
+    rs = np.random.RandomState(M + K + N)
+    x, w, b = rnd(rs, M, K), rnd(rs, N, K, scale=K ** -0.5), rnd(rs, N, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y_ref = F.linear(F.silu(xr) if act else xr, wr, br)
+    gy = rnd(rs, M, N)
+    y_ref.backward(gy)
+    d = dev()
+    xd, wd, bd = (t.to(d).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xd, wd, bd, act_in=act)
+    assert rel_err(y, y_ref) < 1e-5
+    y.backward(gy.to(d))
+    assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(wd.grad, wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+
+
+def test_timestep_embedding_matches_reference_vectors():
+    from dm_hip import ops
+    g = golden("embeddings.npz")
+    for dim in (64, 128):
+        out = ops.timestep_embed(T(g["t"]).to(dev()), T(g[f"freq_{dim}"]).to(dev()))
+        # sin/cos of arguments up to ~1e3 rad: device and host libm agree to a few ulp of the argument
+        assert max_abs(out, T(g[f"enc_{dim}"])) < 2e-6
+
+
+def test_class_embed():
+    from dm_hip import ops
+    rs = np.random.RandomState(5)
+    B, E = 6, 64
+    emb, table = rnd(rs, B, E), rnd(rs, 11, E)
+    cls = T(np.array([0, 3, 9, 9, 1, 10], dtype=np.int64))
+    mask = T(np.array([0, 1, 0, 0, 1, 0], dtype=np.float32))
+    d = dev()
+    for c, m in [(cls, mask), (cls, None), (None, None)]:
+        er, tr = emb.clone().requires_grad_(True), table.clone().requires_grad_(True)
+        idx = torch.full((B,), 10) if c is None else (c if m is None else torch.where(m.bool(), torch.full_like(c, 10), c))
+        ref = er + F.embedding(idx, tr, padding_idx=10)
+        ref.backward(torch.ones_like(ref) * 0.5)
+        ed, td = emb.to(d).requires_grad_(True), table.to(d).requires_grad_(True)
+        out = ops.class_embed_add(ed, td, None if c is None else c.to(d), None if m is None else m.to(d), 10)
+        assert max_abs(out, ref) == 0.0
+        out.backward(torch.ones_like(out) * 0.5)
+        assert max_abs(ed.grad, er.grad) == 0.0 and max_abs(td.grad, tr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("B,Cs,H,W,Cb", [(2, 3, 8, 8, 64), (3, 1, 7, 7, 64), (2, 3, 16, 16, 128), (1, 3, 5, 9, 128)])
+def test_edge_convs(B, Cs, H, W, Cb):
+    from dm_hip import ops
+    rs = np.random.RandomState(B + Cs + H + Cb)
+    d = dev()
+    # image -> features
+    x, w, b = rnd(rs, B, Cs, H, W), rnd(rs, Cb, Cs, 3, 3, scale=0.2), rnd(rs, Cb, scale=0.1)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.conv2d(x, wr, br, padding=1)
+    gy = q(rnd(rs, *y_ref.shape))
+    y_ref.backward(gy)
+    wd, bd = w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    y = ops.in_conv(x.to(d), wd, bd)
+    assert rel_err(y.float(), y_ref) < 4e-3          # one bf16 rounding of the output
+    y.backward(gy.to(d))
+    assert rel_err(wd.grad, wr.grad) < 1e-4 and rel_err(bd.grad, br.grad) < 1e-4
+    # features -> image
+    h, w2, b2 = q(rnd(rs, B, Cb, H, W)), rnd(rs, Cs, Cb, 3, 3, scale=Cb ** -0.5), rnd(rs, Cs, scale=0.1)
+    hr, w2r, b2r = (t.clone().requires_grad_(True) for t in (h, w2, b2))
+    o_ref = F.conv2d(hr, w2r, b2r, padding=1)
+    go = rnd(rs, *o_ref.shape)
+    o_ref.backward(go)
+    hd, w2d, b2d = (t.to(d).requires_grad_(True) for t in (h, w2, b2))
+    o = ops.out_conv(hd, w2d, b2d)
+    assert o.dtype == torch.float32 and rel_err(o, o_ref) < 1e-5
+    o.backward(go.to(d))
+    assert rel_err(hd.grad.float(), hr.grad) < 4e-3
+    assert rel_err(w2d.grad, w2r.grad) < 1e-4 and rel_err(b2d.grad, b2r.grad) < 1e-4
+
+
+def test_resample():
+    from dm_hip import ops
+    rs = np.random.RandomState(3)
+    x = q(rnd(rs, 2, 64, 4, 6))
+    d = dev()
+    for fn, ref in [(ops.upsample2x, lambda t: F.interpolate(t, scale_factor=2, mode="nearest")),
+                    (ops.avgpool2x, lambda t: F.avg_pool2d(t, 2, 2))]:
+        xr = x.clone().requires_grad_(True)
+        y_ref = ref(xr)
+        gy = q(rnd(rs, *y_ref.shape))
+        y_ref.backward(gy)
+        xd = x.to(d).requires_grad_(True)
+        y = fn(xd)
+        assert rel_err(y.float(), y_ref) < 4e-3
+        y.backward(gy.to(d))
+        assert rel_err(xd.grad.float(), xr.grad) < 4e-3
+
+
+def test_diffuse_and_loss_bitexact_vs_reference_vectors():
+    from diffusion.scheduler import get_scheduler
+    from dm_hip import ops
+    g = golden("diffusion.npz")
+    d = dev()
+    x = T(g["x"]).to(d)
+    scheds = {"lin": get_scheduler("beta", schedule="linear"), "cos": get_scheduler("beta", schedule="cosine"),
+              "rf": get_scheduler("rectified_flow")}
+    for k, s in scheds.items():
+        eps, t = T(g[f"eps_{k}"]).to(d), T(g[f"t_{k}"]).to(d)
+        xt = s.diffuse(x, t, eps)
+        assert np.array_equal(xt.cpu().numpy(), g[f"xt_{k}"]), k       # bit-exact
+        pred = 0.5 * xt
+        loss = ops.mse_loss(pred, eps, x=x, mode=1) if k == "rf" else ops.mse_loss(pred, eps, mode=0)
+        assert abs(float(loss) - float(g[f"loss_{k}"])) < 2e-7 * max(1.0, float(g[f"loss_{k}"]))
+    # gradient of the loss
+    p = (0.5 * x).clone().requires_grad_(True)
+    eps = T(g["eps_rf"]).to(d)
+    ops.mse_loss(p, eps, x=x, mode=1).backward()
+    ref = 2 * (p.detach() - (x - eps)) / p.numel()
+    assert rel_err(p.grad, ref) < 1e-6
+
+
+def test_sampler_step_and_cfg_bitexact():
+    from dm_hip import ops
+    rs = np.random.RandomState(11)
+    z, p, n = rnd(rs, 4, 3, 8, 8), rnd(rs, 4, 3, 8, 8), rnd(rs, 4, 3, 8, 8)
+    d = dev()
+    c0, c1, c2, c3 = (float(np.float32(v)) for v in (1.0101, 0.0703, 0.1414, 0.9))
+    f = lambda v: torch.tensor(v, dtype=torch.float32)  # noqa: E731
+    out = ops.sampler_step(z.to(d).clone(), p.to(d), n.to(d), c0, c1, c2, 0.0, 0, False, False)
+    assert torch.equal(out.cpu(), f(c0) * (z - f(c1) * p) + f(c2) * n)
+    out = ops.sampler_step(z.to(d).clone(), p.to(d), None, c0, c1, c2, 0.0, 0, False, False)
+    assert torch.equal(out.cpu(), f(c0) * (z - f(c1) * p))
+    x0 = torch.clip((z - f(c1) * p) / f(c0), -1, 1)
+    out = ops.sampler_step(z.to(d).clone(), p.to(d), None, c0, c1, c2, c3, 1, True, False)
+    assert torch.equal(out.cpu(), f(c2) * x0 + f(c3) * p)
+    out = ops.sampler_step(z.to(d).clone(), p.to(d), None, c0, c1, c2, c3, 1, True, True)
+    assert torch.equal(out.cpu(), x0)
+    out = ops.sampler_step(z.to(d).clone(), p.to(d), None, -0.02, 0, 0, 0, 2, False, False)
+    assert torch.equal(out.cpu(), z - f(-0.02) * p)
+    assert torch.equal(ops.cfg_combine(z.to(d), p.to(d), 2.5).cpu(), z + 2.5 * (p - z))
+
+
+def test_adamw_ema_step_matches_torch():
+    import ctypes
+    from dm_hip import lib, check
+    rs = np.random.RandomState(21)
+    n = 100003
+    p0, g = rnd(rs, n), rnd(rs, n, scale=3.0)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=2e-4, betas=(0.9, 0.99))
+    d = dev()
+    p, m, v, ema = p0.to(d), torch.zeros(n, device=d), torch.zeros(n, device=d), p0.to(d).clone()
+    wb = torch.empty(n, dtype=torch.bfloat16, device=d)
+    partials = torch.empty(lib.dm_sumsq_partials(), device=d)
+    norm = torch.empty(1, device=d)
+    ema_ref = p0.clone()
+    st = torch.cuda.current_stream().cuda_stream
+    for step in range(1, 4):
+        gs = g * (0.5 ** step)
+        ref.grad = gs.clone()
+        tn = torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        decay = 0.0 if step == 1 else min(1 - (1 + (step - 1)) ** -0.75, 0.9999)
+        ema_ref.sub_((1 - decay) * (ema_ref - ref.detach()))
+        gd = gs.to(d)
+        check(lib.dm_grad_norm(gd.data_ptr(), n, partials.data_ptr(), norm.data_ptr(), st))
+        assert abs(float(norm) - float(tn)) < 1e-5 * float(tn)
+        check(lib.dm_adamw_ema_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(),
+                                    wb.data_ptr(), norm.data_ptr(), 1.0, n, 2e-4, 0.9, 0.99, 1e-8, 1e-2,
+                                    1 - 0.9 ** step, 1 - 0.99 ** step, decay, None, st))
+        assert max_abs(p, ref.detach()) < 2e-7
+        assert max_abs(ema, ema_ref) < 2e-7
+        assert torch.equal(wb.float().cpu(), p.cpu().to(torch.bfloat16).float())

@@ -1,0 +1,121 @@
+"""CPU: host-side logic of the drop-in packages and the C-ABI surface (no kernel is launched)."""
+import ctypes
+import re
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.parity import ROOT, contract, golden, load_cfg
+
+
+def test_library_exports_every_declared_symbol():
+    import dm_hip
+    header = open(os.path.join(ROOT, "include", "dm_hip.h")).read()
+    declared = set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"dm_status"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(dm_hip.lib, name), f"{name} declared in include/dm_hip.h but not exported"
+    assert set(dm_hip.EXPORTS) == declared, set(dm_hip.EXPORTS) ^ declared
+    assert dm_hip.lib.dm_abi_version() == 1
+
+
+def test_status_and_error_text_without_gpu():
+    import dm_hip
+    rc = dm_hip.lib.dm_timestep_embed(None, None, None, 0, 0, None)
+    assert rc == 1
+    assert b"dm_timestep_embed" in dm_hip.lib.dm_last_error()
+    d = dm_hip.ConvDesc(1, 8, 8, 48, 0, 64, 3, 3, 1, 1, 0, 0, 8, 8)
+    rc = dm_hip.lib.dm_conv2d_igemm(ctypes.byref(d), 16, None, 16, None, None, 16, None)
+    assert rc == 2 and b"multiples of 64" in dm_hip.lib.dm_last_error()
+    with pytest.raises(dm_hip.DmHipError):
+        dm_hip.check(rc)
+
+
+@pytest.mark.parametrize("name", ["beta_cifar", "cos_cifar", "fid_test", "rf_cifar", "rf_cifar_long", "rf_mnist"])
+def test_configs_load_unchanged_and_state_dict_contract(name):
+    from modeling import get_model
+    from diffusion.scheduler import get_scheduler
+    from diffusion.sampler import get_sampler
+    cfg = load_cfg(name)
+    model = get_model(cfg["model_type"], **cfg["model_cfg"])
+    sched = get_scheduler(cfg["scheduler_type"], **cfg["scheduler_cfg"])
+    sampler = get_sampler(cfg["sampler_type"], **cfg["sampler_cfg"])
+    assert sampler.pred_type == sched.pred_type
+    c = contract()[name]
+    keys = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()]
+    assert keys == c["keys"]
+    assert [k for k, _ in model.named_parameters()] == c["param_names"]
+    assert sum(p.numel() for p in model.parameters()) == c["n_params"]
+    # a reference-layout checkpoint loads with all keys matched
+    sd = {k: torch.zeros(s, dtype=getattr(torch, dt)) for k, s, dt in c["keys"]}
+    assert str(model.load_state_dict(sd)) == "<All keys matched successfully>"
+
+
+def test_factories_reject_unknown_names():
+    from modeling import get_model
+    from modeling.activation import get_activation
+    from modeling.blocks import get_down_block, get_up_block, ConvBlock
+    from diffusion.scheduler import get_scheduler
+    from diffusion.sampler import get_sampler
+    for fn, arg in [(get_model, "resnet"), (get_activation, "tanh"), (get_scheduler, "edm"), (get_sampler, "heun")]:
+        with pytest.raises(ValueError):
+            fn(arg)
+    with pytest.raises(ValueError):
+        get_down_block("NoSuchBlock", 64, 64)
+    with pytest.raises(ValueError):
+        get_up_block("NoSuchBlock", 64, 64, 64)
+    with pytest.raises(ValueError):
+        ConvBlock(64, 64, embedding_dim=64, embedding_mixing="concat")
+    with pytest.raises(ValueError):
+        get_scheduler("beta", schedule="sigmoid")
+
+
+def test_all_block_types_constructible():
+    from modeling.blocks import get_down_block, get_up_block
+    for kind in ("UNetDownBlock", "UNetAttnDownBlock", "EncoderDownBlock", "EncoderAttnDownBlock"):
+        b = get_down_block(kind, 64, 128, n_dim_head=8, embedding_dim=64)
+        assert len(b.blocks) == 2 and b.downsample is not None
+    for kind in ("UNetUpBlock", "UNetAttnUpBlock", "DecoderUpBlock", "DecoderAttnUpBlock"):
+        b = get_up_block(kind, 128, 64, next_out_channels=64, n_dim_head=8, embedding_dim=64)
+        assert len(b.blocks) == 2 and b.upsample is not None
+
+
+def test_schedule_tables_and_grids_match_reference_vectors():
+    from diffusion.scheduler import get_scheduler
+    from diffusion.sampler import timestep_grid
+    g = golden("schedules.npz")
+    lin = get_scheduler("beta", schedule="linear", n_steps=1000)
+    cos = get_scheduler("beta", schedule="cosine", cos_s=0.008, cos_max_beta=0.999, n_steps=1000)
+    rf = get_scheduler("rectified_flow", n_steps=1000)
+    assert np.array_equal(lin.beta.numpy(), g["lin_beta"]) and np.array_equal(lin.alpha_sq.numpy(), g["lin_alpha_sq"])
+    assert np.array_equal(cos.beta.numpy(), g["cos_beta"]) and np.array_equal(cos.alpha_sq.numpy(), g["cos_alpha_sq"])
+    assert np.array_equal(rf.sigmas.numpy(), g["rf_sigmas"])
+    assert lin.n_steps == 1000 and lin.pred_type == "noise" and rf.pred_type == "velocity"
+    sch = lin.get_schedule(torch.from_numpy(g["sched_t"]))
+    assert np.array_equal(sch.alpha_sq.numpy(), g["sched_alpha_sq"])
+    assert np.array_equal(sch.sigma_sq.numpy(), g["sched_sigma_sq"])
+    assert np.array_equal(sch.log_snr.numpy(), g["sched_log_snr"])
+    for a, b in [(1000, 10), (1000, 50), (1000, 1000), (1000, 7), (37, 5), (13, 13), (1000, 1)]:
+        assert np.array_equal(timestep_grid(a, b).numpy(), g[f"tsteps_{a}_{b}"])
+
+
+def test_sampler_api_surface():
+    from diffusion.sampler import BaseSampler, get_sampler
+    s = get_sampler("ddim", n_steps=50, eta=0.0, clip_latent=True, pbar=True)
+    assert s.n_steps == 50 and s.clip_latent and s.pbar and s.pbar_kwargs == {"leave": False}
+    s.set_steps(10)
+    assert s.n_steps == 10
+    assert list(s.prepare_iterator(range(3))) == [0, 1, 2]
+    with pytest.raises(NotImplementedError):
+        BaseSampler(5).sample(torch.zeros(1), None, None)
+
+
+def test_operators_refuse_cpu_tensors():
+    from modeling import get_model
+    from tests.parity import TINY_CFG
+    m = get_model("unet", **TINY_CFG)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(1, 3, 16, 16), torch.zeros(1, dtype=torch.int64))
