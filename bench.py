@@ -1,0 +1,259 @@
+"""Benchmark: CIFAR-10 UNet training step (arg_json/cos_cifar.json, bf16 MFMA compute, batch 128 per GPU) on N
+MI355X GPUs of one node, synthetic data, through the libdm_hip kernels.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = bernoulli/eps/t draws + noising + UNet forward + loss + backward + (all-reduce) + global-norm clip +
+AdamW + EMA, exactly the work of train.py:429-452. Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel family (the implicit-GEMM convolution: forward
+and data-gradient launches) from per-launch HIP-event timings taken in one extra instrumented step after the
+timed region; `cpu_baseline` times the CPU oracle's training step on the host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "diffusion-models_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FWD_GFLOP_PER_IMG = {"cos_cifar": 16.383, "beta_cifar": 16.383, "rf_cifar_long": 16.383, "rf_cifar": 16.2,
+                     "rf_mnist": 3.108, "fid_test": 2.881}
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def load_cfg(name):
+    with open(os.path.join(ROOT, "tests", "golden", "arg_json", name + ".json")) as f:
+        return json.load(f)
+
+
+def build_step(cfg, device, use_ema=True):
+    from modeling import get_model
+    from diffusion.scheduler import get_scheduler
+    from harness.train_step import TrainStep
+    torch.manual_seed(cfg.get("seed", 42))
+    model = get_model(cfg["model_type"], **cfg["model_cfg"]).to(device).train()
+    sched = get_scheduler(cfg["scheduler_type"], **cfg["scheduler_cfg"])
+    step = TrainStep(model, sched, lr=cfg["lr"], betas=(0.9, 0.99), clip_grad_norm=cfg.get("clip_grad_norm", 1.0),
+                     use_ema=cfg.get("use_ema", True) and use_ema, ema_inv_gamma=cfg.get("ema_inv_gamma", 1.0),
+                     ema_power=cfg.get("ema_power", 0.75), p_uncond=cfg.get("p_uncond", 0.2))
+    return model, sched, step
+
+
+def synthetic_batch(cfg, rank, device, batch):
+    g = torch.Generator().manual_seed(42 + rank)
+    c = cfg["model_cfg"]["in_channels"]
+    hw = 28 if cfg["dataset"] == "mnist" else 32
+    x = torch.rand(batch, c, hw, hw, generator=g) * 2 - 1
+    cls = torch.randint(0, 10, (batch,), generator=g)
+    return x.to(device), cls.to(device)
+
+
+class ConvTimer:
+    """Wraps the conv entry points of the C ABI with HIP events on the launching stream."""
+
+    def __init__(self):
+        from dm_hip import lib
+        self.lib = lib
+        self.records = []
+
+    def __enter__(self):
+        self._orig = {n: getattr(self.lib, n) for n in ("dm_conv2d_igemm", "dm_conv2d_wgrad")}
+        for name, fn in self._orig.items():
+            setattr(self.lib, name, self._wrap(name, fn))
+        return self
+
+    def _wrap(self, name, fn):
+        def call(desc, *args):
+            d = desc._obj
+            m = d.B * d.Ho * d.Wo
+            flops = 2.0 * m * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(desc, *args)
+            e1.record()
+            self.records.append((name, flops, e0, e1))
+            return rc
+        return call
+
+    def __exit__(self, *exc):
+        for name, fn in self._orig.items():
+            setattr(self.lib, name, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            s = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            s["launches"] += 1
+            s["flops"] += flops
+            s["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+def cpu_baseline(cfg, budget_s=20.0, batch=16):
+    """The CPU oracle's training step (oracle/unet_oracle.py) on the host cores: a bounded sample."""
+    from modeling import get_model
+    from oracle import unet_oracle as O
+    torch.manual_seed(42)
+    m = get_model(cfg["model_type"], **cfg["model_cfg"])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    names = O.param_names(sd)
+    opt = O.AdamWState({k: sd[k] for k in names}, lr=cfg["lr"])
+    if cfg["scheduler_type"] == "beta":
+        sc = cfg["scheduler_cfg"]
+        beta = O.beta_cosine(sc.get("cos_s", 0.008), sc.get("cos_max_beta", 0.999), sc["n_steps"]) \
+            if sc.get("schedule") == "cosine" else O.beta_linear(n_steps=sc["n_steps"])
+        kind, table = "vp", O.alpha_sq_from_beta(beta)
+    else:
+        kind, table = "rf", O.rf_sigmas(cfg["scheduler_cfg"]["n_steps"])
+    g = torch.Generator().manual_seed(42)
+    c = cfg["model_cfg"]["in_channels"]
+    hw = 28 if cfg["dataset"] == "mnist" else 32
+    x = torch.rand(batch, c, hw, hw, generator=g) * 2 - 1
+    cls = torch.randint(0, 10, (batch,), generator=g)
+    steps, t_total = 0, 0.0
+    for i in range(1000):
+        mask = torch.bernoulli(0.2 * torch.ones_like(cls, dtype=torch.float32), generator=g)
+        eps, t = O.draw_eps_t(x, 1000, g)
+        t0 = time.perf_counter()
+        O.train_step(sd, cfg["model_cfg"], opt, (x, cls, mask, eps, t), kind, table, clip=1.0)
+        dt = time.perf_counter() - t0
+        if i > 0:  # first step is warm-up
+            steps += 1
+            t_total += dt
+            if t_total > budget_s:
+                break
+    return {"value": round(batch * steps / t_total, 3), "unit": "img/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{steps} oracle train steps of {cfg['output_dir'].split('/')[-1]} at batch "
+                                      f"{batch} (fp32, torch CPU primitives) after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="cos_cifar")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's batch_size)")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = load_cfg(args.config)
+    batch = args.batch or cfg["batch_size"]
+    model, sched, step = build_step(cfg, device)
+    x, cls = synthetic_batch(cfg, rank, device, batch)
+
+    from dm_hip import ops
+    graph = None
+    run = lambda: step.step(x, cls)  # noqa: E731
+    # eager warm-up (also primes allocator pools and packed weights)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    if not args.no_graph and world == 1:
+        try:
+            ops.FORCE_REPACK = True
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                run()  # warm-up on the capture stream
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph, stream=side):
+                    loss_static = step.step(x, cls)
+            torch.cuda.current_stream().wait_stream(side)
+            run = graph.replay
+        except Exception as e:  # capture is an optimisation; the eager path is the same kernels
+            sys.stderr.write(f"[bench] graph capture failed, running eagerly: {e!r}\n")
+            graph = None
+            run = lambda: step.step(x, cls)  # noqa: E731
+        finally:
+            ops.FORCE_REPACK = False
+
+    for _ in range(args.warmup):
+        run()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = batch * world * args.steps / elapsed
+
+    # dominant-kernel roofline from one instrumented eager step
+    roof = None
+    if rank == 0:
+        with ConvTimer() as ct:
+            step.step(x, cls)
+        s = ct.summary()
+        ig, wg = s.get("dm_conv2d_igemm"), s.get("dm_conv2d_wgrad")
+        if ig and ig["ms"] > 0:
+            achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
+                    "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": ig["launches"], "ms_per_step": round(ig["ms"], 3),
+                    "wgrad": {"achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2), "launches_per_step": wg["launches"],
+                              "ms_per_step": round(wg["ms"], 3)} if wg and wg["ms"] > 0 else None}
+
+    if rank == 0:
+        step_tflop = 3 * FWD_GFLOP_PER_IMG.get(args.config, 0.0) * batch / 1e3
+        line = {
+            "metric": "train imgs/sec (node) CIFAR-10 UNet",
+            "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"arg_json/{args.config}.json train step (UNet {cfg['model_cfg']['block_out_channels']}, "
+                                   f"{cfg['scheduler_cfg'].get('schedule', cfg['scheduler_type'])} schedule, AdamW+clip+EMA)",
+                       "per_gpu_batch": batch, "global_batch": batch * world, "image": "3x32x32",
+                       "parallelism": f"dp{world}", "hip_graph": graph is not None},
+            "step_tflops_achieved": round(step_tflop / (ms_per_step * 1e-3), 2) if step_tflop else None,
+            "step_mfma_frac": round(step_tflop / (ms_per_step * 1e-3) / MFMA_BF16_PEAK_TFLOPS / world, 4) if step_tflop else None,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, budget_s=args.cpu_budget)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

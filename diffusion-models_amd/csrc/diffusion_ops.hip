@@ -1,8 +1,8 @@
 // Diffusion-process elementwise kernels (fp32, HBM-bound): forward noising, MSE loss and its gradient,
 // the per-step sampler update and the classifier-free-guidance combine.
-// Products and sums are written with explicit roundings (__fmul_rn/__fadd_rn) so the compiler cannot contract
-// them into FMAs: the reference evaluates these expressions as separate fp32 tensor ops, and the sampler
-// update is iterated up to 1000 times.
+// Every product and sum must be rounded separately: the reference evaluates these expressions as separate fp32
+// tensor ops, and the sampler update is iterated up to 1000 times. HIP's __fmul_rn/__fadd_rn are plain
+// operators that the compiler would still contract into FMAs, so this file is built with -ffp-contract=off.
 #include "dm_common.h"
 
 namespace {

@@ -25,8 +25,8 @@ struct GnArgs {
   bf16_t* dx2;
   float* mean;
   float* rstd;
-  float* dgamma_part;
-  float* dbeta_part;
+  float* dgamma;
+  float* dbeta;
   float* dss;
   float* dpre;
   int B, HW, C1, C2, C, G, cg, CS, act;
@@ -198,8 +198,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_kernel(GnArgs a) {
     const int ch = c0 + i;
     const float av = s_a[i], bv = s_b[i];
     const float scv = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + ch] : 1.f;
-    a.dbeta_part[(size_t)b * a.C + ch] = scv * av;
-    a.dgamma_part[(size_t)b * a.C + ch] = scv * bv;
+    atomicAdd(a.dbeta + ch, scv * av);
+    atomicAdd(a.dgamma + ch, scv * bv);
     if (a.dss) {
       a.dss[(size_t)b * 2 * a.C + ch] = a.gamma[ch] * bv + a.beta[ch] * av;
       a.dss[(size_t)b * 2 * a.C + a.C + ch] = av;
@@ -296,11 +296,11 @@ extern "C" int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const v
 extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma,
                                     const float* beta, const float* scale_shift, const float* pre_add,
                                     const float* mean, const float* rstd, const void* dy, const void* dextra,
-                                    void* dx1, void* dx2, float* dgamma_part, float* dbeta_part,
+                                    void* dx1, void* dx2, float* dgamma, float* dbeta,
                                     float* dscale_shift, float* dpre_add, void* stream) {
   int rc = check_desc(d, "dm_groupnorm_act_bwd");
   if (rc) return rc;
-  DM_REQUIRE(x1 && gamma && beta && mean && rstd && dy && dx1 && dgamma_part && dbeta_part, DM_ERR_ARG,
+  DM_REQUIRE(x1 && gamma && beta && mean && rstd && dy && dx1 && dgamma && dbeta, DM_ERR_ARG,
              "dm_groupnorm_act_bwd: null argument");
   DM_REQUIRE((d->C2 == 0) == (x2 == nullptr) && (d->C2 == 0) == (dx2 == nullptr), DM_ERR_ARG, "dm_groupnorm_act_bwd: x2/dx2 and C2 disagree");
   DM_REQUIRE((d->has_ss != 0) == (scale_shift != nullptr) && (d->has_ss != 0) == (dscale_shift != nullptr), DM_ERR_ARG,
@@ -312,7 +312,7 @@ extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const v
   GnArgs a = {};
   a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.pre = pre_add;
   a.mean_in = mean; a.rstd_in = rstd; a.dy = (const bf16_t*)dy; a.dextra = (const bf16_t*)dextra;
-  a.dx1 = (bf16_t*)dx1; a.dx2 = (bf16_t*)dx2; a.dgamma_part = dgamma_part; a.dbeta_part = dbeta_part;
+  a.dx1 = (bf16_t*)dx1; a.dx2 = (bf16_t*)dx2; a.dgamma = dgamma; a.dbeta = dbeta;
   a.dss = dscale_shift; a.dpre = dpre_add;
   a.B = d->B; a.HW = d->HW; a.C1 = d->C1; a.C2 = d->C2; a.C = d->C1 + d->C2; a.G = d->G; a.cg = a.C / a.G;
   a.CS = pick_slab(a.B, a.C, a.cg); a.act = d->act; a.eps = d->eps;

@@ -49,14 +49,14 @@ __global__ __launch_bounds__(NT) void adamw_ema_kernel(float* __restrict__ p, co
     clip = clip < 1.f ? clip : 1.f;
   }
   const float step_size = lr / bc1;
-  const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  const float sqrt_bc2 = sqrtf(bc2);
   const float omd = 1.f - ema_decay;
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
     const float gi = g[i] * clip;
     float pi = p[i] * (1.f - lr * wd);
     const float mi = m[i] + (1.f - b1) * (gi - m[i]);
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
     pi -= step_size * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
     if (ema) { const float e = ema[i]; ema[i] = e - omd * (e - pi); }

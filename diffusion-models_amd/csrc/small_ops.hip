@@ -53,34 +53,70 @@ __global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict_
   }
 }
 
-// dx[m][k] = f'(x[m][k]) * sum_n dy[m][n] w[n][k]; one block per row m
-__global__ void linear_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
-                                    float* __restrict__ dx, int M, int K, int N, int act_in) {
-  const int m = blockIdx.x;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += dy[(size_t)m * N + n] * w[(size_t)n * K + k];
-    if (act_in) s *= dm_silu_grad(x[(size_t)m * K + k]);
-    dx[(size_t)m * K + k] = s;
+// dx[m][k] = f'(x[m][k]) * sum_n dy[m][n] w[n][k]; block = 4 rows x 64 columns, n streamed through LDS in chunks
+constexpr int BX_ROWS = 4, BX_COLS = 64, BX_CHUNK = 32;
+__global__ __launch_bounds__(NT) void linear_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ dy, float* __restrict__ dx, int M,
+                                                          int K, int N, int act_in) {
+  __shared__ float sdy[BX_ROWS][BX_CHUNK];
+  __shared__ float sw[BX_CHUNK][BX_COLS];
+  const int k0 = blockIdx.x * BX_COLS, m0 = blockIdx.y * BX_ROWS;
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int n0 = 0; n0 < N; n0 += BX_CHUNK) {
+    __syncthreads();
+    if (threadIdx.x < BX_ROWS * BX_CHUNK) {
+      const int rr = threadIdx.x / BX_CHUNK, nn = threadIdx.x % BX_CHUNK;
+      sdy[rr][nn] = (m0 + rr < M && n0 + nn < N) ? dy[(size_t)(m0 + rr) * N + n0 + nn] : 0.f;
+    }
+    for (int i = threadIdx.x; i < BX_CHUNK * BX_COLS; i += NT) {
+      const int nn = i / BX_COLS, cc = i % BX_COLS;
+      sw[nn][cc] = (n0 + nn < N && k0 + cc < K) ? w[(size_t)(n0 + nn) * K + k0 + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nn = 0; nn < BX_CHUNK; ++nn) acc += sdy[r][nn] * sw[nn][c];
+  }
+  const int m = m0 + r, k = k0 + c;
+  if (m < M && k < K) {
+    if (act_in) acc *= dm_silu_grad(x[(size_t)m * K + k]);
+    dx[(size_t)m * K + k] = acc;
   }
 }
 
-// dw[n][k] += sum_m dy[m][n] f(x[m][k]); dbias[n] += sum_m dy[m][n]; one block per output row n
-__global__ void linear_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                    float* __restrict__ dbias, int M, int K, int N, int act_in) {
-  const int n = blockIdx.x;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    float s = 0.f;
-    for (int m = 0; m < M; ++m) {
-      float xv = x[(size_t)m * K + k];
-      s += dy[(size_t)m * N + n] * (act_in ? dm_silu(xv) : xv);
+// dw[n][k] += sum_m dy[m][n] f(x[m][k]); dbias[n] += sum_m dy[m][n]; block = 4 output rows x 64 columns,
+// the 4 dy columns staged in LDS, x read coalesced along k
+constexpr int BW_ROWS = 4, BW_COLS = 64, BW_MAXM = 512;
+__global__ __launch_bounds__(NT) void linear_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dw, float* __restrict__ dbias, int M, int K,
+                                                          int N, int act_in) {
+  __shared__ float sdy[BW_MAXM][BW_ROWS];
+  const int k0 = blockIdx.x * BW_COLS, n0 = blockIdx.y * BW_ROWS;
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int k = k0 + c, n = n0 + r;
+  float acc = 0.f, bsum = 0.f;
+  for (int mb = 0; mb < M; mb += BW_MAXM) {
+    const int mc = min(BW_MAXM, M - mb);
+    __syncthreads();
+    for (int i = threadIdx.x; i < mc * BW_ROWS; i += NT) {
+      const int mm = i / BW_ROWS, rr = i % BW_ROWS;
+      sdy[mm][rr] = (n0 + rr < N) ? dy[(size_t)(mb + mm) * N + n0 + rr] : 0.f;
     }
-    if (dw) dw[(size_t)n * K + k] += s;
+    __syncthreads();
+    if (k < K) {
+#pragma unroll 4
+      for (int mm = 0; mm < mc; ++mm) {
+        float xv = x[(size_t)(mb + mm) * K + k];
+        if (act_in) xv = dm_silu(xv);
+        acc += sdy[mm][r] * xv;
+      }
+    }
+    if (dbias && blockIdx.x == 0 && c == 0)
+      for (int mm = 0; mm < mc; ++mm) bsum += sdy[mm][r];
   }
-  if (dbias && threadIdx.x == 0) {
-    float s = 0.f;
-    for (int m = 0; m < M; ++m) s += dy[(size_t)m * N + n];
-    dbias[n] += s;
+  if (n < N) {
+    if (dw && k < K) dw[(size_t)n * K + k] += acc;
+    if (dbias && blockIdx.x == 0 && c == 0) dbias[n] += bsum;
   }
 }
 
@@ -175,20 +211,31 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, long s_co, long 
 // ---- column sums
 __global__ __launch_bounds__(NT) void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long M,
                                                          int C, int rows_per_block) {
+  // per-thread partial sums over this block's rows, combined across the block in LDS: one atomic per column per
+  // block (many blocks adding to the same few addresses is what makes naive column sums slow)
+  __shared__ float red[NT * 8];
   const int VP = C >> 3, PL = NT / VP;
   const int v = threadIdx.x % VP, pl = threadIdx.x / VP;
-  if (pl >= PL) return;
   const long m0 = (long)blockIdx.x * rows_per_block;
   const long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (long m = m0 + pl; m < m1; m += PL) {
-    float f[8];
-    dm_unpack8(*(const bf16x8_t*)(x + m * C + 8 * v), f);
+  if (pl < PL) {
+    for (long m = m0 + pl; m < m1; m += PL) {
+      float f[8];
+      dm_unpack8(*(const bf16x8_t*)(x + m * C + 8 * v), f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] += f[j];
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) atomicAdd(out + 8 * v + j, acc[j]);
+  for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[j];
+  __syncthreads();
+  for (int col = threadIdx.x; col < C; col += NT) {
+    const int vv = col >> 3, j = col & 7;
+    float sum = 0.f;
+    for (int q = 0; q < PL; ++q) sum += red[(q * VP + vv) * 8 + j];
+    atomicAdd(out + col, sum);
+  }
 }
 __global__ void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -221,13 +268,14 @@ extern "C" int dm_linear_fwd(const float* x, const float* w, const float* bias, 
 extern "C" int dm_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias, int M,
                              int K, int N, int act_in, void* stream) {
   DM_REQUIRE(x && w && dy && M > 0 && K > 0 && N > 0, DM_ERR_ARG, "dm_linear_bwd: bad argument");
-  const int nt = K >= 256 ? 256 : (K >= 128 ? 128 : 64);
   if (dx) {
-    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(M), dim3(nt), 0, (hipStream_t)stream, x, w, dy, dx, M, K, N, act_in);
+    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(dm_cdiv(K, BX_COLS), dm_cdiv(M, BX_ROWS)), dim3(NT), 0, (hipStream_t)stream,
+                       x, w, dy, dx, M, K, N, act_in);
     DM_CHECK_LAUNCH();
   }
   if (dw || dbias) {
-    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(N), dim3(nt), 0, (hipStream_t)stream, x, dy, dw, dbias, M, K, N, act_in);
+    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(dm_cdiv(K, BW_COLS), dm_cdiv(N, BW_ROWS)), dim3(NT), 0, (hipStream_t)stream,
+                       x, dy, dw, dbias, M, K, N, act_in);
     DM_CHECK_LAUNCH();
   }
   return DM_OK;
@@ -304,8 +352,8 @@ extern "C" int dm_pack_conv_weight(const float* w, long s_co, long s_ci, long s_
 extern "C" int dm_colsum_bf16(const void* x, float* out, long M, int C, void* stream) {
   DM_REQUIRE(x && out && M > 0 && C > 0, DM_ERR_ARG, "dm_colsum_bf16: bad argument");
   DM_REQUIRE(C % 8 == 0 && C / 8 <= NT, DM_ERR_SHAPE, "dm_colsum_bf16: C=%d must be a multiple of 8 and <= %d", C, NT * 8);
-  int rpb = 256;
-  while (dm_cdiv(M, rpb) > 1024) rpb *= 2;
+  int rpb = 64;
+  while (dm_cdiv(M, rpb) > 256) rpb *= 2;
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(dm_cdiv(M, rpb)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, out, M, C, rpb);
   DM_CHECK_LAUNCH();
   return DM_OK;

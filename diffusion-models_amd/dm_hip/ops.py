@@ -20,6 +20,11 @@ FORCE_REPACK = False
 # Bumped by whoever rewrites parameter memory behind torch's back (the fused optimizer kernel); part of the
 # pack cache key, since such writes do not advance tensor._version.
 WEIGHTS_EPOCH = 0
+# When True, parameter gradients are accumulated by the kernels straight into an existing fp32 `param.grad`
+# (e.g. a view of a flat gradient arena) instead of being returned to autograd as fresh tensors: no zero-fill, no
+# extra add pass. GRAD_READY(param), if set, is told when such a gradient has been enqueued.
+DIRECT_GRADS = False
+GRAD_READY = None
 
 
 def _stream():
@@ -57,6 +62,27 @@ def as_nhwc(x):
 
 def empty_nhwc(B, C, H, W, device):
     return torch.empty_strided((B, C, H, W), (H * W * C, 1, W * C, C), dtype=BF16, device=device)
+
+
+def _grad_sink(param, ohwi=False):
+    """The tensor a kernel may accumulate this parameter's gradient into directly, or None."""
+    if not DIRECT_GRADS or param is None:
+        return None
+    g = param.grad
+    if g is None or g.dtype != torch.float32 or not g.is_cuda:
+        return None
+    if ohwi and g.dim() == 4:
+        co, ci, kh, kw = g.shape
+        if g.stride() != (kh * kw * ci, 1, kw * ci, ci):
+            return None
+    elif not g.is_contiguous():
+        return None
+    return g
+
+
+def _grad_done(param):
+    if GRAD_READY is not None:
+        GRAD_READY(param)
 
 
 def f32c(t):
@@ -121,6 +147,7 @@ class _ConvFn(Function):
         check(lib.dm_conv2d_igemm(ctypes.byref(d), x1.data_ptr(), _p(x2), w_fwd.data_ptr(), _p(b32), _p(res),
                                   y.data_ptr(), _stream()))
         ctx.save_for_backward(x1, x2, weight)
+        ctx.params = (weight, bias)
         ctx.cfg = (stride, pad, ups, pack, bias is not None, res is not None, (B, C1, C2, Hs, Ws, Hi, Wi, Ho, Wo))
         return y
 
@@ -148,16 +175,26 @@ class _ConvFn(Function):
                 dx1 = dxf
             else:
                 dx1, dx2 = dxf[:, :C1], dxf[:, C1:]
+        wparam, bparam = ctx.params
         if ctx.needs_input_grad[2]:
-            dwf = torch.zeros((Cout, KH, KW, Cin), dtype=torch.float32, device=dy.device)
+            sink = _grad_sink(wparam, ohwi=True)
+            dwf = sink if sink is not None else torch.zeros((Cout, KH, KW, Cin), dtype=torch.float32, device=dy.device)
             d = _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, 0, Ho, Wo)
             check(lib.dm_conv2d_wgrad(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(), st))
-            dw = dwf.permute(0, 3, 1, 2)
-            if weight.dim() == 2:
-                dw = dw.reshape(Cout, Cin)
+            if sink is not None:
+                _grad_done(wparam)
+            else:
+                dw = dwf.permute(0, 3, 1, 2)
+                if weight.dim() == 2:
+                    dw = dw.reshape(Cout, Cin)
         if has_bias and ctx.needs_input_grad[3]:
-            db = torch.zeros(Cout, dtype=torch.float32, device=dy.device)
-            check(lib.dm_colsum_bf16(dy.data_ptr(), db.data_ptr(), B * Ho * Wo, Cout, st))
+            sink = _grad_sink(bparam)
+            dbf = sink if sink is not None else torch.zeros(Cout, dtype=torch.float32, device=dy.device)
+            check(lib.dm_colsum_bf16(dy.data_ptr(), dbf.data_ptr(), B * Ho * Wo, Cout, st))
+            if sink is not None:
+                _grad_done(bparam)
+            else:
+                db = dbf
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
         return dx1, dx2, dw, db, dres, None, None, None, None
 
@@ -191,6 +228,7 @@ class _GroupNormActFn(Function):
                                        _p(ss32), _p(pre32), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                        _stream()))
         ctx.save_for_backward(x1, x2, g32, b32, ss32, pre32, mean, rstd)
+        ctx.params = (gamma, beta)
         ctx.cfg = (d, B, C1, C2, H, W)
         return y
 
@@ -203,19 +241,25 @@ class _GroupNormActFn(Function):
         dev = dy.device
         dx1 = empty_nhwc(B, C1, H, W, dev)
         dx2 = empty_nhwc(B, C2, H, W, dev) if x2 is not None else None
-        dgp = torch.empty((B, C), dtype=torch.float32, device=dev)
-        dbp = torch.empty((B, C), dtype=torch.float32, device=dev)
+        gs, bs = _grad_sink(ctx.params[0]), _grad_sink(ctx.params[1])
+        direct = gs is not None and bs is not None
+        if direct:
+            dg, db_ = gs, bs
+        else:
+            dgb = torch.zeros((2, C), dtype=torch.float32, device=dev)
+            dg, db_ = dgb[0], dgb[1]
         dss = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if ss32 is not None else None
         dpre = torch.empty((B, C), dtype=torch.float32, device=dev) if pre32 is not None else None
         st = _stream()
         check(lib.dm_groupnorm_act_bwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
                                        _p(ss32), _p(pre32), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), None,
-                                       dx1.data_ptr(), _p(dx2), dgp.data_ptr(), dbp.data_ptr(), _p(dss), _p(dpre),
-                                       st))
-        dgb = torch.zeros((2, C), dtype=torch.float32, device=dev)
-        check(lib.dm_colsum_f32(dgp.data_ptr(), dgb[0].data_ptr(), B, C, st))
-        check(lib.dm_colsum_f32(dbp.data_ptr(), dgb[1].data_ptr(), B, C, st))
-        return dx1, dx2, dgb[0], dgb[1], dss, dpre, None, None, None
+                                       dx1.data_ptr(), _p(dx2), dg.data_ptr(), db_.data_ptr(), _p(dss),
+                                       _p(dpre), st))
+        if direct:
+            _grad_done(ctx.params[0])
+            _grad_done(ctx.params[1])
+            return dx1, dx2, None, None, dss, dpre, None, None, None
+        return dx1, dx2, dg, db_, dss, dpre, None, None, None
 
 
 def group_norm_act(x1, gamma, beta, groups, eps, act, x2=None, scale_shift=None, pre_add=None):
@@ -269,6 +313,7 @@ class _LinearFn(Function):
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         check(lib.dm_linear_fwd(x32.data_ptr(), w32.data_ptr(), _p(b32), y.data_ptr(), M, K, N, int(act_in), _stream()))
         ctx.save_for_backward(x32, w32)
+        ctx.params = (weight, bias)
         ctx.cfg = (M, K, N, int(act_in), bias is not None)
         return y
 
@@ -279,10 +324,22 @@ class _LinearFn(Function):
         dy = f32c(dy)
         dev = dy.device
         dx = torch.empty((M, K), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
-        dw = torch.zeros((N, K), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
-        db = torch.zeros((N,), dtype=torch.float32, device=dev) if (has_bias and ctx.needs_input_grad[2]) else None
+        wparam, bparam = ctx.params
+        dw = db = ws = bs = None
+        if ctx.needs_input_grad[1]:
+            ws = _grad_sink(wparam)
+            dw = ws if ws is not None else torch.zeros((N, K), dtype=torch.float32, device=dev)
+        if has_bias and ctx.needs_input_grad[2]:
+            bs = _grad_sink(bparam)
+            db = bs if bs is not None else torch.zeros((N,), dtype=torch.float32, device=dev)
         check(lib.dm_linear_bwd(x32.data_ptr(), w32.data_ptr(), dy.data_ptr(), _p(dx), _p(dw), _p(db), M, K, N, act_in,
                                 _stream()))
+        if ws is not None:
+            _grad_done(wparam)
+            dw = None
+        if bs is not None:
+            _grad_done(bparam)
+            db = None
         return dx, dw, db, None
 
 

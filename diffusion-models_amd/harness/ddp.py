@@ -1,0 +1,75 @@
+"""Bucketed gradient all-reduce over a flat gradient arena, overlapped with backward.
+
+The gradient arena is one contiguous fp32 buffer holding every parameter's gradient at a fixed offset
+(registration order). It is cut into contiguous buckets walking the parameters in REVERSE registration order -
+roughly the order in which backward produces them - and a bucket's all-reduce is launched the moment every
+parameter inside it has reported its gradient, while backward is still running on the remaining layers.
+On MI355X nodes the backend is RCCL over xGMI ("nccl" in torch.distributed); the same code runs over gloo on
+CPU tensors, which is how the multi-process tests exercise it.
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def cut_buckets(offsets: Sequence[int], total: int, bucket_elems: int) -> List[Tuple[int, int]]:
+    """[lo, hi) element ranges covering [0, total), boundaries on parameter offsets, each >= bucket_elems
+    (except possibly the one that ends at parameter 0), listed from the END of the arena to its start."""
+    buckets, hi = [], total
+    for i in range(len(offsets) - 1, -1, -1):
+        lo = offsets[i]
+        if hi - lo >= bucket_elems or i == 0:
+            if hi > lo:
+                buckets.append((lo, hi))
+            hi = lo
+    return buckets
+
+
+class BucketedAllReduce:
+    def __init__(self, grad_arena: torch.Tensor, offsets: Sequence[int], bucket_bytes: int = 25 << 20, group=None):
+        self.grad = grad_arena
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.buckets = cut_buckets(offsets, grad_arena.numel(), max(1, bucket_bytes // grad_arena.element_size()))
+        self.bucket_of, self.size = {}, [0] * len(self.buckets)
+        for i, o in enumerate(offsets):
+            for b, (lo, hi) in enumerate(self.buckets):
+                if lo <= o < hi:
+                    self.bucket_of[i] = b
+                    self.size[b] += 1
+                    break
+        self.begin()
+
+    def begin(self):
+        """Call before backward."""
+        self.ready, self.launched, self.handles = set(), set(), []
+        self.count = [0] * len(self.buckets)
+
+    def on_ready(self, param_index: int):
+        """Parameter `param_index`'s gradient has been enqueued. Launches its bucket when the bucket is complete."""
+        if self.world == 1 or param_index in self.ready:
+            return
+        self.ready.add(param_index)
+        b = self.bucket_of[param_index]
+        self.count[b] += 1
+        if self.count[b] == self.size[b]:
+            self._launch(b)
+
+    def _launch(self, b):
+        lo, hi = self.buckets[b]
+        self.handles.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launched.add(b)
+
+    def finish(self):
+        """Call after backward: reduces buckets whose parameters never all reported (unused parameters), waits,
+        and turns the sums into means."""
+        if self.world == 1:
+            return
+        for b in range(len(self.buckets)):
+            if b not in self.launched:
+                self._launch(b)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        self.grad.mul_(1.0 / self.world)

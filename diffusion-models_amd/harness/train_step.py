@@ -20,6 +20,7 @@ import torch
 import torch.distributed as dist
 
 from dm_hip import check, lib, ops
+from harness.ddp import BucketedAllReduce
 from modeling.layers import Conv2d
 
 _ALIGN = 64  # floats: every parameter starts on a 256-byte boundary
@@ -53,19 +54,6 @@ class FlatArena:
             p.data = view
             p.grad = gview
 
-    def grad_slices(self, bucket_bytes: int):
-        """Contiguous [start, end) element ranges of the gradient arena, walking parameters in REVERSE
-        registration order, each about bucket_bytes; with the index of the first-registered parameter of each."""
-        buckets, end, cur_first = [], self.numel, None
-        limit = max(1, bucket_bytes // 4)
-        hi = self.numel
-        for i in range(len(self.params) - 1, -1, -1):
-            start = self.offsets[i]
-            if hi - start >= limit or i == 0:
-                buckets.append((start, hi, i))
-                hi = start
-        return buckets
-
 
 class TrainStep:
     def __init__(self, model, scheduler, lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2,
@@ -87,53 +75,33 @@ class TrainStep:
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
         self.steps = 0
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self._buckets = self.arena.grad_slices(bucket_mb << 20)
-        self._handles = []
+        self.reducer = BucketedAllReduce(self.arena.grad, self.arena.offsets, bucket_mb << 20, process_group)
+        self.world = self.reducer.world
+        self._in_backward = False
+        self._param_index = {id(p): i for i, (_, p) in enumerate(self.arena.params)}
         if self.world > 1:
-            self._install_overlap_hooks()
+            # gradients that autograd accumulates itself report through this hook; gradients the kernels write in
+            # place report through ops.GRAD_READY (set around backward)
+            for _, p in self.arena.params:
+                p.register_post_accumulate_grad_hook(self._on_grad_ready)
 
-    # ---- data-parallel gradient averaging, overlapped with backward --------------------------------------
-    def _install_overlap_hooks(self):
-        first_param_to_bucket = {first: b for b, (_, _, first) in enumerate(self._buckets)}
-        params = self.arena.params
-
-        def make_hook(idx):
-            def hook(_p):
-                # Gradients arrive in reverse registration order; when the FIRST-registered parameter of a bucket
-                # has its gradient, the whole contiguous slice is final and its all-reduce can start.
-                b = first_param_to_bucket.get(idx)
-                if b is not None and self._overlap_enabled:
-                    self._launch_bucket(b)
-            return hook
-
-        self._overlap_enabled = True
-        for i, (_, p) in enumerate(params):
-            p.register_post_accumulate_grad_hook(make_hook(i))
-
-    def _launch_bucket(self, b):
-        lo, hi, _ = self._buckets[b]
-        self._handles.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                             async_op=True))
-        self._launched.add(b)
-
-    def _finish_allreduce(self):
-        if self.world == 1:
-            return
-        for b in range(len(self._buckets)):  # parameters that received no gradient never fired their hook
-            if b not in self._launched:
-                self._launch_bucket(b)
-        for h in self._handles:
-            h.wait()
-        self._handles.clear()
-        self.arena.grad.mul_(1.0 / self.world)
+    def _on_grad_ready(self, p):
+        if self._in_backward:
+            i = self._param_index.get(id(p))
+            if i is not None:
+                self.reducer.on_ready(i)
 
     # ---- one step ----------------------------------------------------------------------------------------
     def _backward_and_update(self, loss):
-        self._launched = set()
-        loss.backward()
-        self._finish_allreduce()
+        self.reducer.begin()
+        self._in_backward = True
+        ops.DIRECT_GRADS, ops.GRAD_READY = True, (self._on_grad_ready if self.world > 1 else None)
+        try:
+            loss.backward()
+        finally:
+            ops.DIRECT_GRADS, ops.GRAD_READY = False, None
+            self._in_backward = False
+        self.reducer.finish()
         a = self.arena
         st = torch.cuda.current_stream().cuda_stream
         if self.clip > 0:

@@ -112,12 +112,12 @@ typedef struct dm_gn_desc {
 int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma, const float* beta,
                          const float* scale_shift, const float* pre_add, void* y, float* mean, float* rstd,
                          void* stream);
-/* dx1|dx2 bf16 (= GN backward + dextra, dextra optional bf16 [B][HW][C]); dgamma_part/dbeta_part fp32 [B][C]
- * (per-sample partials, to be column-summed); dscale_shift fp32 [B][2C] and dpre_add fp32 [B][C] when present */
+/* dx1|dx2 bf16 (= GN backward + dextra, dextra optional bf16 [B][HW][C]); dgamma/dbeta fp32 [C] ACCUMULATE
+ * (atomics); dscale_shift fp32 [B][2C] and dpre_add fp32 [B][C] are written when present */
 int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma, const float* beta,
                          const float* scale_shift, const float* pre_add, const float* mean, const float* rstd,
-                         const void* dy, const void* dextra, void* dx1, void* dx2, float* dgamma_part,
-                         float* dbeta_part, float* dscale_shift, float* dpre_add, void* stream);
+                         const void* dy, const void* dextra, void* dx1, void* dx2, float* dgamma, float* dbeta,
+                         float* dscale_shift, float* dpre_add, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Spatial self-attention core. Replaces F.scaled_dot_product_attention and the view/permute/contiguous

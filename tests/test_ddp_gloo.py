@@ -1,0 +1,73 @@
+"""CPU, world_size 2 over gloo: the bucketed, backward-overlapped gradient all-reduce of the training harness."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.parity import PKG, ROOT
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from harness.ddp import BucketedAllReduce, cut_buckets
+        sizes = [7, 1000, 64, 3000, 5, 128, 4096, 9, 640]
+        offsets, off = [], 0
+        for n in sizes:
+            offsets.append(off)
+            off += (n + 63) // 64 * 64
+        total = off
+        g = torch.Generator().manual_seed(100 + rank)
+        grads = torch.randn(total, generator=g)
+        expect = sum(torch.randn(total, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
+        red = BucketedAllReduce(grads, offsets, bucket_bytes=4 * 2000)
+        assert red.world == world and len(red.buckets) > 2
+        # gradients become ready in a scrambled, rank-identical order; one parameter never reports
+        order = [8, 6, 7, 5, 3, 4, 1, 2]
+        red.begin()
+        for i in order:
+            red.on_ready(i)
+            red.on_ready(i)  # duplicate notifications are ignored
+        launched_early = len(red.launched)
+        red.finish()
+        ok = torch.allclose(grads, expect, atol=1e-6)
+        q.put((rank, ok, launched_early, len(red.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cut_buckets_partition():
+    sys.path.insert(0, PKG)
+    from harness.ddp import cut_buckets
+    offsets = [0, 64, 1088, 1152, 4160]
+    total = 4224
+    b = cut_buckets(offsets, total, 1000)
+    assert b[0][1] == total and b[-1][0] == 0
+    for (lo, hi), (lo2, hi2) in zip(b, b[1:]):
+        assert hi2 == lo            # contiguous, walking towards the start of the arena
+    assert all(lo in offsets for lo, _ in b)
+    assert all(hi - lo >= 1000 for lo, hi in b[:-1])
+    assert cut_buckets([0], 10, 1 << 20) == [(0, 10)]
+
+
+def test_bucketed_allreduce_world2():
+    world, port = 2, 29611
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    for rank, ok, early, nb in res:
+        assert ok, f"rank {rank}: averaged gradients wrong"
+        assert 0 < early < nb, "some (not all) buckets must have been launched before finish()"

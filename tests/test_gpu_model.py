@@ -157,39 +157,58 @@ def test_classifier_free_guidance_branches():
             assert rel_err(m.get_pred_fn(**kw)(z, t), T(g[key])) < NET_FWD, key
 
 
-def test_samplers_bitexact_with_analytic_predictor():
+def _close_to_reference(out, ref):
+    # The golden vectors were produced by torch CPU kernels on another host; torch's vectorised fp32 sqrt /
+    # reciprocal are not correctly rounded on every CPU (the coefficient tables move by 1 ulp between hosts), so
+    # against the stored vectors the comparison is to a few ulps per step ...
+    assert rel_err(out, ref) < 5e-6, rel_err(out, ref)
+
+
+def test_samplers_vs_oracle_bitexact_and_reference_vectors():
+    """... while against the CPU oracle evaluated on THIS host (same host-side tables) the loops are bit-exact."""
     from diffusion.scheduler import get_scheduler
     from diffusion.sampler import get_sampler
+    from oracle import unet_oracle as O
     g = golden("diffusion.npz")
-    z = T(g["z"]).to(dev())
+    zc = T(g["z"])
+    z = zc.to(dev())
     pred = lambda z_, t_: 0.1 * z_ + 1e-6 * t_.view(-1, 1, 1, 1)  # noqa: E731
     lin, cos = get_scheduler("beta", schedule="linear"), get_scheduler("beta", schedule="cosine")
     rf = get_scheduler("rectified_flow")
-    for key, out in [
-        ("euler50", get_sampler("euler", n_steps=50).sample(z, rf, pred)),
-        ("euler7", get_sampler("euler", n_steps=7).sample(z, rf, pred)),
-        ("ddim50_lin", get_sampler("ddim", n_steps=50).sample(z, lin, pred)),
-        ("ddim50_cos", get_sampler("ddim", n_steps=50).sample(z, cos, pred)),
-        ("ddim10_cos_noclip", get_sampler("ddim", n_steps=10, clip_latent=False).sample(z, cos, pred)),
-    ]:
-        # pred is evaluated by torch on the device: mul/add of fp32 tensors, same roundings as on the host
-        assert np.array_equal(out.cpu().numpy(), g[key]), (key, max_abs(out, T(g[key])))
+    cases = [
+        ("euler50", get_sampler("euler", n_steps=50).sample(z, rf, pred), O.sample_euler(zc, O.rf_sigmas(), 50, pred)),
+        ("euler7", get_sampler("euler", n_steps=7).sample(z, rf, pred), O.sample_euler(zc, O.rf_sigmas(), 7, pred)),
+        ("ddim50_lin", get_sampler("ddim", n_steps=50).sample(z, lin, pred),
+         O.sample_ddim(zc, O.alpha_sq_from_beta(O.beta_linear()), 50, pred)),
+        ("ddim50_cos", get_sampler("ddim", n_steps=50).sample(z, cos, pred),
+         O.sample_ddim(zc, O.alpha_sq_from_beta(O.beta_cosine()), 50, pred)),
+        ("ddim10_cos_noclip", get_sampler("ddim", n_steps=10, clip_latent=False).sample(z, cos, pred),
+         O.sample_ddim(zc, O.alpha_sq_from_beta(O.beta_cosine()), 10, pred, clip_latent=False)),
+    ]
+    for key, out, ora in cases:
+        assert torch.equal(out.cpu(), ora), (key, max_abs(out, ora))
+        _close_to_reference(out, T(g[key]))
 
 
 def test_ddpm_sampler_with_injected_noise_and_determinism(monkeypatch):
     from diffusion.scheduler import get_scheduler
     from diffusion.sampler import get_sampler
+    from oracle import unet_oracle as O
     g = golden("diffusion.npz")
     d = dev()
-    z = T(g["z"]).to(d)
+    zc = T(g["z"])
+    z = zc.to(d)
     pred = lambda z_, t_: 0.1 * z_ + 1e-6 * t_.view(-1, 1, 1, 1)  # noqa: E731
     cos = get_scheduler("beta", schedule="cosine")
-    noise = T(g["noise_ddpm20_cos_seed3"]).to(d)
+    noise_c = T(g["noise_ddpm20_cos_seed3"])
+    noise = noise_c.to(d)
     it = iter(range(noise.shape[0]))
     monkeypatch.setattr(torch, "randn_like", lambda t_, generator=None: noise[next(it)])
     out = get_sampler("ddpm", n_steps=20).sample(z, cos, pred, seed=3)
     monkeypatch.undo()
-    assert np.array_equal(out.cpu().numpy(), g["ddpm20_cos_seed3"])
+    ora = O.sample_ddpm(zc, O.beta_cosine(), O.alpha_sq_from_beta(O.beta_cosine()), 20, pred, lambda i: noise_c[i])
+    assert torch.equal(out.cpu(), ora)
+    _close_to_reference(out, T(g["ddpm20_cos_seed3"]))
     # device generator semantics: unseeded calls repeat the same noise; a seed changes it
     s = get_sampler("ddpm", n_steps=10)
     a, b, c = s.sample(z, cos, pred), s.sample(z, cos, pred), s.sample(z, cos, pred, seed=7)

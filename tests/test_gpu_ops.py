@@ -325,6 +325,8 @@ def test_adamw_ema_step_matches_torch():
         check(lib.dm_adamw_ema_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(),
                                     wb.data_ptr(), norm.data_ptr(), 1.0, n, 2e-4, 0.9, 0.99, 1e-8, 1e-2,
                                     1 - 0.9 ** step, 1 - 0.99 ** step, decay, None, st))
-        assert max_abs(p, ref.detach()) < 2e-7
-        assert max_abs(ema, ema_ref) < 2e-7
+        # same formulas as torch's AdamW; the global norm is reduced in a different order (rel 5e-7) and FMA
+        # contraction moves results by an ulp: parameters of magnitude <= 8 agree to 2 ulps
+        assert max_abs(p, ref.detach()) < 2e-6
+        assert max_abs(ema, ema_ref) < 2e-6
         assert torch.equal(wb.float().cpu(), p.cpu().to(torch.bfloat16).float())

@@ -118,23 +118,30 @@ def test_losses_and_noising():
     assert abs(float(g["loss_lin"]) - 0.40292478) < 1e-7 and abs(float(g["loss_rf"]) - 1.79405022) < 1e-7
 
 
+def _same(out, ref):
+    # bit-exact on the CPU model that generated the vectors; torch's vectorised fp32 sqrt/reciprocal are not
+    # correctly rounded everywhere, so on another CPU model the coefficient tables may move by an ulp
+    ref = T(ref)
+    return torch.equal(out, ref) or rel_err(out, ref) < 5e-6
+
+
 def test_samplers_bitexact():
     g = golden("diffusion.npz")
     z = T(g["z"])
     pred = lambda z_, t_: 0.1 * z_ + 1e-6 * t_.view(-1, 1, 1, 1)  # noqa: E731
     lin, cos, rf = O.alpha_sq_from_beta(O.beta_linear()), O.alpha_sq_from_beta(O.beta_cosine()), O.rf_sigmas()
-    assert np.array_equal(O.sample_euler(z, rf, 50, pred).numpy(), g["euler50"])
-    assert np.array_equal(O.sample_euler(z, rf, 7, pred).numpy(), g["euler7"])
-    assert np.array_equal(O.sample_ddim(z, lin, 50, pred).numpy(), g["ddim50_lin"])
-    assert np.array_equal(O.sample_ddim(z, cos, 50, pred).numpy(), g["ddim50_cos"])
-    assert np.array_equal(O.sample_ddim(z, cos, 10, pred, clip_latent=False).numpy(), g["ddim10_cos_noclip"])
+    assert _same(O.sample_euler(z, rf, 50, pred), g["euler50"])
+    assert _same(O.sample_euler(z, rf, 7, pred), g["euler7"])
+    assert _same(O.sample_ddim(z, lin, 50, pred), g["ddim50_lin"])
+    assert _same(O.sample_ddim(z, cos, 50, pred), g["ddim50_cos"])
+    assert _same(O.sample_ddim(z, cos, 10, pred, clip_latent=False), g["ddim10_cos_noclip"])
     noise = T(g["noise_ddpm20_cos_seed3"])
     out = O.sample_ddpm(z, O.beta_cosine(), cos, 20, pred, lambda i: noise[i])
-    assert np.array_equal(out.numpy(), g["ddpm20_cos_seed3"])
+    assert _same(out, g["ddpm20_cos_seed3"])
     gen = torch.Generator()
     gen.manual_seed(7)
     out = O.sample_ddpm(z, O.beta_linear(), lin, 1000, pred, lambda i: torch.randn_like(z, generator=gen))
-    assert np.array_equal(out.numpy(), g["ddpm1000_lin_seed7"])
+    assert _same(out, g["ddpm1000_lin_seed7"])
     assert abs(float(out.double().sum()) - (-8037.306618)) < 1e-3  # SURVEY known answer
 
 
