@@ -114,37 +114,37 @@ __global__ __launch_bounds__(NT) void big_to_small_kernel(const bf16_t* __restri
 // big_is_output = 1 (in_conv):  dw[cb][cs][tap], sg = +1, dbias[cb] += sum_m big[m][cb]
 // big_is_output = 0 (out_conv): dw[cs][cb][tap], sg = -1, dbias[cs] += sum_m small[b][cs][h][w]
 constexpr int WG_PIX = 64;
+template <int CS>
 __global__ __launch_bounds__(NT) void edge_wgrad_kernel(const float* __restrict__ small, const bf16_t* __restrict__ big,
-                                                        float* __restrict__ dw, float* __restrict__ dbias, int B, int Cs,
-                                                        int H, int W, int Cb, int big_is_output, int pix_per_block) {
+                                                        float* __restrict__ dw, float* __restrict__ dbias, int B, int H,
+                                                        int W, int Cb, int big_is_output, int pix_per_block) {
+  constexpr int K = CS * 9;
+  constexpr int KP = (K + 1 + 3) / 4 * 4;  // taps + a column of ones (bias), padded to float4
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int K = Cs * 9;
-  float* S = lds;                     // [K+1][WG_PIX]  (last row: ones / unused)
-  float* Bt = lds + (K + 1) * WG_PIX;  // [WG_PIX][Cb]
+  float* S = lds;                 // [WG_PIX][KP]
+  float* Bt = lds + WG_PIX * KP;  // [WG_PIX][Cb]
   const int sg = big_is_output ? 1 : -1;
   const int M = B * H * W;
-  const int KG = NT / Cb;             // k-groups (Cb <= 256 so KG >= 1)
-  const int cb = threadIdx.x % Cb, kg = threadIdx.x / Cb;
-  const bool active = kg < KG;
-  float acc[28];
+  const int NPG = NT / Cb;        // pixel groups: thread = (feature channel cb, pixel group pg)
+  const int cb = threadIdx.x % Cb, pg = threadIdx.x / Cb;
+  float acc[KP];
 #pragma unroll
-  for (int i = 0; i < 28; ++i) acc[i] = 0.f;
-  float bsum = 0.f;  // per-thread bias partial
+  for (int i = 0; i < KP; ++i) acc[i] = 0.f;
   const int m_begin = blockIdx.x * pix_per_block;
   const int m_end = min(M, m_begin + pix_per_block);
   for (int m0 = m_begin; m0 < m_end; m0 += WG_PIX) {
     __syncthreads();
-    for (int i = threadIdx.x; i < (K + 1) * WG_PIX; i += NT) {
-      const int k = i / WG_PIX, px = i - k * WG_PIX;
+    for (int i = threadIdx.x; i < WG_PIX * KP; i += NT) {
+      const int px = i / KP, k = i - px * KP;
       const int m = m0 + px;
       float val = 0.f;
       if (m < m_end) {
         if (k == K) val = 1.f;
-        else {
+        else if (k < K) {
           const int cs = k / 9, tap = k - cs * 9, kh = tap / 3, kw = tap - kh * 3;
           const int b = m / (H * W), r = m - b * H * W, h = r / W, x = r - h * W;
           const int ih = h + sg * (kh - 1), iw = x + sg * (kw - 1);
-          if (ih >= 0 && iw >= 0 && ih < H && iw < W) val = small[((size_t)b * Cs + cs) * H * W + ih * W + iw];
+          if (ih >= 0 && iw >= 0 && ih < H && iw < W) val = small[((size_t)b * CS + cs) * H * W + ih * W + iw];
         }
       }
       S[i] = val;
@@ -158,35 +158,50 @@ __global__ __launch_bounds__(NT) void edge_wgrad_kernel(const float* __restrict_
       for (int j = 0; j < 8; ++j) Bt[px * Cb + 8 * v + j] = f[j];
     }
     __syncthreads();
-    if (active) {
-      for (int px = 0; px < WG_PIX; ++px) {
-        const float bvv = Bt[px * Cb + cb];
+    if (pg < NPG) {
+      for (int px = pg; px < WG_PIX; px += NPG) {
+        const float bv = Bt[px * Cb + cb];
+        const f32x4_t* sp = (const f32x4_t*)(S + px * KP);  // same address in every lane: an LDS broadcast
 #pragma unroll
-        for (int i = 0; i < 28; ++i) {
-          const int k = kg + i * KG;
-          if (k <= K) acc[i] += bvv * S[k * WG_PIX + px];
+        for (int q = 0; q < KP / 4; ++q) {
+          const f32x4_t sv = sp[q];
+          acc[4 * q + 0] += bv * sv[0];
+          acc[4 * q + 1] += bv * sv[1];
+          acc[4 * q + 2] += bv * sv[2];
+          acc[4 * q + 3] += bv * sv[3];
         }
       }
     }
-    if (!big_is_output && threadIdx.x < Cs) {
-      // centre tap (kh = kw = 1) of channel cs is the unshifted image value
-      for (int px = 0; px < WG_PIX; ++px) bsum += S[(threadIdx.x * 9 + 4) * WG_PIX + px];
-    }
   }
-  if (active) {
+  if (pg < NPG) {
 #pragma unroll
-    for (int i = 0; i < 28; ++i) {
-      const int k = kg + i * KG;
-      if (k < K) {
-        const int cs = k / 9, tap = k - cs * 9;
-        const size_t o = big_is_output ? ((size_t)(cb * Cs + cs) * 9 + tap) : ((size_t)(cs * Cb + cb) * 9 + tap);
-        atomicAdd(dw + o, acc[i]);
-      } else if (k == K && big_is_output && dbias) {
-        atomicAdd(dbias + cb, acc[i]);
-      }
+    for (int k = 0; k < K; ++k) {
+      const int cs = k / 9, tap = k - cs * 9;
+      const size_t o = big_is_output ? ((size_t)(cb * CS + cs) * 9 + tap) : ((size_t)(cs * Cb + cb) * 9 + tap);
+      atomicAdd(dw + o, acc[k]);
     }
+    if (big_is_output && dbias) atomicAdd(dbias + cb, acc[K]);
   }
-  if (!big_is_output && dbias && threadIdx.x < Cs) atomicAdd(dbias + threadIdx.x, bsum);
+  if (!big_is_output && dbias) {
+    // out_conv bias: sum of the image-side gradient itself = centre tap (kh = kw = 1) of each channel
+    __syncthreads();
+    float* red = lds;
+    float part[CS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) part[cs] = 0.f;
+    for (int m = m_begin + threadIdx.x; m < m_end; m += NT) {
+      const int b = m / (H * W), r = m - b * H * W;
+#pragma unroll
+      for (int cs = 0; cs < CS; ++cs) part[cs] += small[((size_t)b * CS + cs) * H * W + r];
+    }
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+      const float t = dm_wave_sum(part[cs]);
+      if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * CS + cs] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < CS) atomicAdd(dbias + threadIdx.x, red[threadIdx.x] + red[CS + threadIdx.x] + red[2 * CS + threadIdx.x] + red[3 * CS + threadIdx.x]);
+  }
 }
 
 int check_edge(const char* who, int B, int Cs, int H, int W, int Cb) {
@@ -243,12 +258,21 @@ extern "C" int dm_edge_conv_wgrad(const float* small, const void* big, float* dw
   if (rc) return rc;
   DM_REQUIRE(small && big && dw, DM_ERR_ARG, "dm_edge_conv_wgrad: null argument");
   DM_REQUIRE(Cb <= 256, DM_ERR_UNSUPPORTED, "dm_edge_conv_wgrad: feature width %d > 256", Cb);
-  DM_REQUIRE((Cs * 9 + 1 + (NT / Cb) - 1) / (NT / Cb) <= 28, DM_ERR_UNSUPPORTED, "dm_edge_conv_wgrad: too many taps per thread");
-  const int M = B * H * W, ppb = 256;
-  const int lds = ((Cs * 9 + 1) * WG_PIX + WG_PIX * Cb) * 4;
+  const int M = B * H * W;
+  int ppb = 1024;
+  while (ppb > WG_PIX && dm_cdiv(M, ppb) < 128) ppb /= 2;
+  const int kp = (Cs * 9 + 1 + 3) / 4 * 4;
+  const int lds = (WG_PIX * kp + WG_PIX * Cb) * 4;
   DM_REQUIRE(lds <= 65536, DM_ERR_UNSUPPORTED, "dm_edge_conv_wgrad: feature width %d exceeds 64 KiB of LDS", Cb);
-  hipLaunchKernelGGL(edge_wgrad_kernel, dim3(dm_cdiv(M, ppb)), dim3(NT), lds, (hipStream_t)stream, small,
-                     (const bf16_t*)big, dw, dbias, B, Cs, H, W, Cb, big_is_output, ppb);
+  dim3 grid(dm_cdiv(M, ppb)), block(NT);
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* bg = (const bf16_t*)big;
+  switch (Cs) {
+    case 1: hipLaunchKernelGGL(edge_wgrad_kernel<1>, grid, block, lds, st, small, bg, dw, dbias, B, H, W, Cb, big_is_output, ppb); break;
+    case 2: hipLaunchKernelGGL(edge_wgrad_kernel<2>, grid, block, lds, st, small, bg, dw, dbias, B, H, W, Cb, big_is_output, ppb); break;
+    case 3: hipLaunchKernelGGL(edge_wgrad_kernel<3>, grid, block, lds, st, small, bg, dw, dbias, B, H, W, Cb, big_is_output, ppb); break;
+    default: hipLaunchKernelGGL(edge_wgrad_kernel<4>, grid, block, lds, st, small, bg, dw, dbias, B, H, W, Cb, big_is_output, ppb); break;
+  }
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

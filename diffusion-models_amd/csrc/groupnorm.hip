@@ -1,13 +1,22 @@
 // Fused GroupNorm (+ per-sample scale/shift or pre-add) (+ SiLU), forward and backward, NHWC bf16.
-// HBM-bound: one workgroup owns one (sample, channel slab); the slab is read from HBM once and re-read from L2
-// for the second/third sweep. Channel slabs are whole groups and whole 8-channel (16-byte) vectors, so every
-// access is a 16-byte piece of a pixel row and the channel axis may be split over two source tensors (x1 | x2).
+//
+// HBM-bound streaming design. Every kernel walks whole pixel rows (all C channels of a pixel are contiguous, so
+// accesses are 16-byte pieces of full rows) with (sample, pixel-chunk) workgroups, i.e. thousands of independent
+// workgroups regardless of the tensor shape:
+//   forward   1. per-(sample, channel) sum and sum of squares  -> fp32 atomics into a [B][2][C] workspace
+//             2. every workgroup derives its sample's group statistics from that workspace (a few hundred
+//                flops) and streams y = act(ka[c] * x + kb[c])
+//   backward  1. per-(sample, channel) sums of du and du * xhat -> workspace
+//             2. group sums from the workspace, then dx streamed; the first pixel-chunk of each sample also emits
+//                the parameter-side gradients (dgamma/dbeta atomics, dscale_shift, dpre_add)
+// The second sweep of each pair re-reads a tensor that was just read, which the 256 MiB Infinity Cache serves.
+// The channel axis may be the concatenation of two tensors (x1 | x2).
 #include "dm_common.h"
 
 namespace {
 
 constexpr int NT = 256;
-constexpr int MAXCS = 1024;
+constexpr int MAXC = 1024;
 
 struct GnArgs {
   const bf16_t* x1;
@@ -16,11 +25,9 @@ struct GnArgs {
   const float* beta;
   const float* ss;
   const float* pre;
-  const float* mean_in;
-  const float* rstd_in;
   const bf16_t* dy;
   const bf16_t* dextra;
-  bf16_t* y;     // fwd output
+  bf16_t* y;
   bf16_t* dx1;
   bf16_t* dx2;
   float* mean;
@@ -29,233 +36,284 @@ struct GnArgs {
   float* dbeta;
   float* dss;
   float* dpre;
-  int B, HW, C1, C2, C, G, cg, CS, act;
+  float* ws;
+  int B, HW, C1, C2, C, G, cg, act, pch;
   float eps;
 };
 
-__device__ __forceinline__ bf16x8_t load_x(const GnArgs& a, int b, int p, int c) {
-  if (c < a.C1) return *(const bf16x8_t*)(a.x1 + ((size_t)b * a.HW + p) * a.C1 + c);
-  return *(const bf16x8_t*)(a.x2 + ((size_t)b * a.HW + p) * a.C2 + (c - a.C1));
+__device__ __forceinline__ bf16x8_t load_x(const GnArgs& a, size_t pix, int c) {
+  if (c < a.C1) return *(const bf16x8_t*)(a.x1 + pix * a.C1 + c);
+  return *(const bf16x8_t*)(a.x2 + pix * a.C2 + (c - a.C1));
 }
 
-__global__ __launch_bounds__(NT) void gn_fwd_kernel(GnArgs a) {
-  __shared__ float s_a[MAXCS];
-  __shared__ float s_b[MAXCS];
-  __shared__ float s_mean[MAXCS];
-  __shared__ float s_rstd[MAXCS];
-  const int b = blockIdx.y, c0 = blockIdx.x * a.CS;
-  const int tid = threadIdx.x;
-  const int VP = a.CS >> 3, PL = NT / VP;
-  const bool active = tid < PL * VP;
-  const int v = tid % VP, pl = tid / VP;
-  const int cl = 8 * v, c = c0 + cl;
-  for (int i = tid; i < a.CS; i += NT) { s_a[i] = 0.f; s_b[i] = 0.f; }
-  __syncthreads();
+// thread -> (8-channel vector v, pixel lane pl); threads beyond PL*VP idle
+struct Lanes {
+  int VP, PL, v, pl;
+  bool active;
+  __device__ Lanes(int C) {
+    VP = C >> 3;
+    PL = NT / VP;
+    v = threadIdx.x % VP;
+    pl = threadIdx.x / VP;
+    active = pl < PL;
+  }
+};
 
-  float pre[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) pre[j] = (a.pre && active) ? a.pre[(size_t)b * a.C + c + j] : 0.f;
-
-  // sweep 1: per-channel sums
-  if (active) {
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = pl; p < a.HW; p += PL) {
-      float f[8];
-      dm_unpack8(load_x(a, b, p, c), f);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s[j] += f[j] + pre[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&s_a[cl + j], s[j]);
-  }
+// combine per-thread partials red[tid][NV][8] over pixel lanes and add them to out[k*C + c]
+template <int NV>
+__device__ __forceinline__ void reduce_to_global(float* red, const Lanes& L, int C, float* out) {
   __syncthreads();
-  const int ngs = a.CS / a.cg;
-  const float inv_n = 1.0f / (float)(a.cg * a.HW);
-  for (int g = tid; g < ngs; g += NT) {
-    float t = 0.f;
-    for (int j = 0; j < a.cg; ++j) t += s_a[g * a.cg + j];
-    s_mean[g] = t * inv_n;
-  }
-  __syncthreads();
-  float mu[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) mu[j] = active ? s_mean[(cl + j) / a.cg] : 0.f;
-  // sweep 2: centred second moment
-  if (active) {
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = pl; p < a.HW; p += PL) {
-      float f[8];
-      dm_unpack8(load_x(a, b, p, c), f);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { float d = f[j] + pre[j] - mu[j]; s[j] += d * d; }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&s_b[cl + j], s[j]);
-  }
-  __syncthreads();
-  for (int gl = tid; gl < ngs; gl += NT) {
-    float t = 0.f;
-    for (int j = 0; j < a.cg; ++j) t += s_b[gl * a.cg + j];
-    float r = rsqrtf(t * inv_n + a.eps);
-    s_rstd[gl] = r;
-    const int g = c0 / a.cg + gl;
-    a.mean[(size_t)b * a.G + g] = s_mean[gl];
-    a.rstd[(size_t)b * a.G + g] = r;
-  }
-  __syncthreads();
-  if (!active) return;
-  // sweep 3: normalise, affine, scale/shift, activation
-  float ka[8], kb[8];  // y = act(ka * xin + kb)
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float r = s_rstd[(cl + j) / a.cg];
-    float ga = a.gamma[c + j], be = a.beta[c + j];
-    float sc = 1.f, sh = 0.f;
-    if (a.ss) { sc = 1.f + a.ss[(size_t)b * 2 * a.C + c + j]; sh = a.ss[(size_t)b * 2 * a.C + a.C + c + j]; }
-    // u = sc * (ga * (x - mu) * r + be) + sh
-    ka[j] = sc * ga * r;
-    kb[j] = sc * (be - ga * r * mu[j]) + sh + ka[j] * pre[j];
-  }
-  for (int p = pl; p < a.HW; p += PL) {
-    float f[8];
-    dm_unpack8(load_x(a, b, p, c), f);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float u = ka[j] * f[j] + kb[j];
-      f[j] = a.act ? dm_silu(u) : u;
-    }
-    *(bf16x8_t*)(a.y + ((size_t)b * a.HW + p) * a.C + c) = dm_pack8(f);
+  for (int i = threadIdx.x; i < NV * C; i += NT) {
+    const int k = i / C, c = i - k * C;
+    const int vv = c >> 3, j = c & 7;
+    float s = 0.f;
+    for (int q = 0; q < L.PL; ++q) s += red[((q * L.VP + vv) * NV + k) * 8 + j];
+    atomicAdd(out + (size_t)k * C + c, s);
   }
 }
 
-__global__ __launch_bounds__(NT) void gn_bwd_kernel(GnArgs a) {
-  __shared__ float s_a[MAXCS];
-  __shared__ float s_b[MAXCS];
-  __shared__ float s_c[MAXCS];
-  __shared__ float s_A[MAXCS];
-  __shared__ float s_B[MAXCS];
-  const int b = blockIdx.y, c0 = blockIdx.x * a.CS;
-  const int tid = threadIdx.x;
-  const int VP = a.CS >> 3, PL = NT / VP;
-  const bool active = tid < PL * VP;
-  const int v = tid % VP, pl = tid / VP;
-  const int cl = 8 * v, c = c0 + cl;
-  for (int i = tid; i < a.CS; i += NT) { s_a[i] = 0.f; s_b[i] = 0.f; s_c[i] = 0.f; }
-  __syncthreads();
-
-  // per-channel constants: xhat = (x + pre - mu) * r ; u = sc * (ga * xhat + be) + sh
-  float pre[8], mu[8], r[8], ga[8], be[8], sc[8], sh[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (active) {
-      const int g = (c + j) / a.cg;
-      pre[j] = a.pre ? a.pre[(size_t)b * a.C + c + j] : 0.f;
-      mu[j] = a.mean_in[(size_t)b * a.G + g];
-      r[j] = a.rstd_in[(size_t)b * a.G + g];
-      ga[j] = a.gamma[c + j];
-      be[j] = a.beta[c + j];
-      sc[j] = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + c + j] : 1.f;
-      sh[j] = a.ss ? a.ss[(size_t)b * 2 * a.C + a.C + c + j] : 0.f;
-    } else {
-      pre[j] = mu[j] = r[j] = ga[j] = be[j] = sh[j] = 0.f; sc[j] = 1.f;
-    }
-  }
-  // sweep 1: a_c = sum du, b_c = sum du * xhat
-  if (active) {
-    float sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = pl; p < a.HW; p += PL) {
-      float f[8], d[8];
-      dm_unpack8(load_x(a, b, p, c), f);
-      dm_unpack8(*(const bf16x8_t*)(a.dy + ((size_t)b * a.HW + p) * a.C + c), d);
+// ---- forward sweep 1: ws[b][0][c] += sum x, ws[b][1][c] += sum x^2 over this chunk
+__global__ __launch_bounds__(NT) void gn_stats_kernel(GnArgs a) {
+  __shared__ float red[NT * 2 * 8];
+  const int b = blockIdx.y, p0 = blockIdx.x * a.pch;
+  const int p1 = min(a.HW, p0 + a.pch);
+  const Lanes L(a.C);
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (L.active) {
+    const int c = 8 * L.v;
+    const size_t base = (size_t)b * a.HW;
+    int p = p0 + L.pl;
+    for (; p + 3 * L.PL < p1; p += 4 * L.PL) {
+      bf16x8_t r0 = load_x(a, base + p, c), r1 = load_x(a, base + p + L.PL, c);
+      bf16x8_t r2 = load_x(a, base + p + 2 * L.PL, c), r3 = load_x(a, base + p + 3 * L.PL, c);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float xh = (f[j] + pre[j] - mu[j]) * r[j];
-        float u = sc[j] * (ga[j] * xh + be[j]) + sh[j];
-        float du = a.act ? d[j] * dm_silu_grad(u) : d[j];
-        sa[j] += du;
-        sb[j] += du * xh;
+        const float f0 = (float)r0[j], f1 = (float)r1[j], f2 = (float)r2[j], f3 = (float)r3[j];
+        s1[j] += (f0 + f1) + (f2 + f3);
+        s2[j] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
       }
     }
+    for (; p < p1; p += L.PL) {
+      bf16x8_t r0 = load_x(a, base + p, c);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { atomicAdd(&s_a[cl + j], sa[j]); atomicAdd(&s_b[cl + j], sb[j]); }
+      for (int j = 0; j < 8; ++j) { const float f0 = (float)r0[j]; s1[j] += f0; s2[j] += f0 * f0; }
+    }
   }
-  __syncthreads();
-  const int ngs = a.CS / a.cg;
-  for (int gl = tid; gl < ngs; gl += NT) {
-    float A = 0.f, Bv = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[(threadIdx.x * 2 + 0) * 8 + j] = s1[j]; red[(threadIdx.x * 2 + 1) * 8 + j] = s2[j]; }
+  reduce_to_global<2>(red, L, a.C, a.ws + (size_t)b * 2 * a.C);
+}
+
+// group statistics of sample b from the channel sums (with the pre-add folded in analytically)
+__device__ __forceinline__ void group_stats(const GnArgs& a, int b, float* s_mean, float* s_rstd, bool write_out) {
+  const float* w1 = a.ws + (size_t)b * 2 * a.C;
+  const float* w2 = w1 + a.C;
+  for (int g = threadIdx.x; g < a.G; g += NT) {
+    float t1 = 0.f, t2 = 0.f;
     for (int j = 0; j < a.cg; ++j) {
-      int ch = c0 + gl * a.cg + j;
-      float k = a.gamma[ch] * (a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + ch] : 1.f);
-      A += k * s_a[gl * a.cg + j];
-      Bv += k * s_b[gl * a.cg + j];
+      const int c = g * a.cg + j;
+      float u1 = w1[c], u2 = w2[c];
+      if (a.pre) {
+        const float pv = a.pre[(size_t)b * a.C + c];
+        u2 += 2.f * pv * u1 + (float)a.HW * pv * pv;
+        u1 += (float)a.HW * pv;
+      }
+      t1 += u1;
+      t2 += u2;
     }
     const float inv_n = 1.0f / (float)(a.cg * a.HW);
-    s_A[gl] = A * inv_n;
-    s_B[gl] = Bv * inv_n;
-  }
-  // per-channel parameter-side gradients of this sample
-  for (int i = tid; i < a.CS; i += NT) {
-    const int ch = c0 + i;
-    const float av = s_a[i], bv = s_b[i];
-    const float scv = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + ch] : 1.f;
-    atomicAdd(a.dbeta + ch, scv * av);
-    atomicAdd(a.dgamma + ch, scv * bv);
-    if (a.dss) {
-      a.dss[(size_t)b * 2 * a.C + ch] = a.gamma[ch] * bv + a.beta[ch] * av;
-      a.dss[(size_t)b * 2 * a.C + a.C + ch] = av;
-    }
-  }
-  __syncthreads();
-  // sweep 2: dx
-  if (active) {
-    float Ag[8], Bg[8], sp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { Ag[j] = s_A[(cl + j) / a.cg]; Bg[j] = s_B[(cl + j) / a.cg]; }
-    for (int p = pl; p < a.HW; p += PL) {
-      float f[8], d[8], e[8];
-      dm_unpack8(load_x(a, b, p, c), f);
-      const size_t o = ((size_t)b * a.HW + p) * a.C + c;
-      dm_unpack8(*(const bf16x8_t*)(a.dy + o), d);
-      if (a.dextra) dm_unpack8(*(const bf16x8_t*)(a.dextra + o), e);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float xh = (f[j] + pre[j] - mu[j]) * r[j];
-        float u = sc[j] * (ga[j] * xh + be[j]) + sh[j];
-        float du = a.act ? d[j] * dm_silu_grad(u) : d[j];
-        float dxv = r[j] * (sc[j] * ga[j] * du - Ag[j] - xh * Bg[j]);
-        sp[j] += dxv;
-        f[j] = a.dextra ? dxv + e[j] : dxv;
-      }
-      bf16x8_t ov = dm_pack8(f);
-      if (c < a.C1) *(bf16x8_t*)(a.dx1 + ((size_t)b * a.HW + p) * a.C1 + c) = ov;
-      else *(bf16x8_t*)(a.dx2 + ((size_t)b * a.HW + p) * a.C2 + (c - a.C1)) = ov;
-    }
-    if (a.dpre) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(&s_c[cl + j], sp[j]);
-    }
-  }
-  if (a.dpre) {
-    __syncthreads();
-    for (int i = tid; i < a.CS; i += NT) a.dpre[(size_t)b * a.C + c0 + i] = s_c[i];
+    const float m = t1 * inv_n;
+    const float var = fmaxf(t2 * inv_n - m * m, 0.f);
+    const float r = rsqrtf(var + a.eps);
+    s_mean[g] = m;
+    s_rstd[g] = r;
+    if (write_out) { a.mean[(size_t)b * a.G + g] = m; a.rstd[(size_t)b * a.G + g] = r; }
   }
 }
 
-int gcd_i(int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; }
-
-// channels per slab: whole groups, whole 8-channel vectors, enough workgroups to fill the chip
-int pick_slab(int B, int C, int cg) {
-  const int unit = cg / gcd_i(cg, 8) * 8;
-  int best = 0;
-  for (int nslab = 1; nslab <= C / unit; ++nslab) {
-    if (C % nslab) continue;
-    const int cs = C / nslab;
-    if (cs % unit || cs > MAXCS) continue;
-    if (cs < 32 && best) break;  // keep at least 64-byte pieces of a pixel row per slab
-    best = cs;
-    if ((long)B * nslab >= 768) break;
+// ---- forward sweep 2: y = act(ka * x + kb)
+__global__ __launch_bounds__(NT) void gn_apply_kernel(GnArgs a) {
+  __shared__ float s_mean[256], s_rstd[256];
+  __shared__ float s_ka[MAXC], s_kb[MAXC];
+  const int b = blockIdx.y, p0 = blockIdx.x * a.pch;
+  const int p1 = min(a.HW, p0 + a.pch);
+  group_stats(a, b, s_mean, s_rstd, blockIdx.x == 0);
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += NT) {
+    const int g = c / a.cg;
+    const float r = s_rstd[g], mu = s_mean[g];
+    const float ga = a.gamma[c], be = a.beta[c];
+    float sc = 1.f, sh = 0.f;
+    if (a.ss) { sc = 1.f + a.ss[(size_t)b * 2 * a.C + c]; sh = a.ss[(size_t)b * 2 * a.C + a.C + c]; }
+    const float pv = a.pre ? a.pre[(size_t)b * a.C + c] : 0.f;
+    const float ka = sc * ga * r;
+    s_ka[c] = ka;
+    s_kb[c] = ka * (pv - mu) + sc * be + sh;  // u = sc * (ga * (x + pre - mu) * r + be) + sh
   }
-  return best;
+  __syncthreads();
+  const Lanes L(a.C);
+  if (!L.active) return;
+  const int c = 8 * L.v;
+  float ka[8], kb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ka[j] = s_ka[c + j]; kb[j] = s_kb[c + j]; }
+  const size_t base = (size_t)b * a.HW;
+  auto emit = [&](const bf16x8_t& r, int p) {
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float u = ka[j] * (float)r[j] + kb[j];
+      f[j] = a.act ? dm_silu(u) : u;
+    }
+    *(bf16x8_t*)(a.y + (base + p) * a.C + c) = dm_pack8(f);
+  };
+  int p = p0 + L.pl;
+  for (; p + 3 * L.PL < p1; p += 4 * L.PL) {
+    bf16x8_t r0 = load_x(a, base + p, c), r1 = load_x(a, base + p + L.PL, c);
+    bf16x8_t r2 = load_x(a, base + p + 2 * L.PL, c), r3 = load_x(a, base + p + 3 * L.PL, c);
+    emit(r0, p); emit(r1, p + L.PL); emit(r2, p + 2 * L.PL); emit(r3, p + 3 * L.PL);
+  }
+  for (; p < p1; p += L.PL) emit(load_x(a, base + p, c), p);
+}
+
+// per-channel constants of sample b for the backward: xhat = xa * x + xb, u = ua * x + ub, k = sc * gamma, r
+__device__ __forceinline__ void bwd_constants(const GnArgs& a, int b, float* s_xa, float* s_xb, float* s_ua, float* s_ub) {
+  for (int c = threadIdx.x; c < a.C; c += NT) {
+    const int g = c / a.cg;
+    const float r = a.rstd[(size_t)b * a.G + g], mu = a.mean[(size_t)b * a.G + g];
+    const float pv = a.pre ? a.pre[(size_t)b * a.C + c] : 0.f;
+    const float sc = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + c] : 1.f;
+    const float sh = a.ss ? a.ss[(size_t)b * 2 * a.C + a.C + c] : 0.f;
+    const float xa = r, xb = (pv - mu) * r;
+    s_xa[c] = xa;
+    s_xb[c] = xb;
+    s_ua[c] = sc * a.gamma[c] * xa;
+    s_ub[c] = sc * (a.gamma[c] * xb + a.beta[c]) + sh;
+  }
+}
+
+// ---- backward sweep 1: ws[b][0][c] += sum du, ws[b][1][c] += sum du*xhat, (ws[b][2][c] += sum xhat if pre-add)
+__global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(GnArgs a) {
+  __shared__ float red[NT * 3 * 8];
+  __shared__ float s_xa[MAXC], s_xb[MAXC], s_ua[MAXC], s_ub[MAXC];
+  const int b = blockIdx.y, p0 = blockIdx.x * a.pch;
+  const int p1 = min(a.HW, p0 + a.pch);
+  bwd_constants(a, b, s_xa, s_xb, s_ua, s_ub);
+  __syncthreads();
+  const Lanes L(a.C);
+  float sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (L.active) {
+    const int c = 8 * L.v;
+    float xa[8], xb[8], ua[8], ub[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { xa[j] = s_xa[c + j]; xb[j] = s_xb[c + j]; ua[j] = s_ua[c + j]; ub[j] = s_ub[c + j]; }
+    const size_t base = (size_t)b * a.HW;
+    auto acc = [&](const bf16x8_t& xr, const bf16x8_t& dr) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xv = (float)xr[j];
+        const float xh = xa[j] * xv + xb[j];
+        const float du = a.act ? (float)dr[j] * dm_silu_grad(ua[j] * xv + ub[j]) : (float)dr[j];
+        sa[j] += du;
+        sb[j] += du * xh;
+        sx[j] += xh;
+      }
+    };
+    int p = p0 + L.pl;
+    for (; p + L.PL < p1; p += 2 * L.PL) {
+      bf16x8_t x0 = load_x(a, base + p, c), x1 = load_x(a, base + p + L.PL, c);
+      bf16x8_t d0 = *(const bf16x8_t*)(a.dy + (base + p) * a.C + c);
+      bf16x8_t d1 = *(const bf16x8_t*)(a.dy + (base + p + L.PL) * a.C + c);
+      acc(x0, d0);
+      acc(x1, d1);
+    }
+    for (; p < p1; p += L.PL) acc(load_x(a, base + p, c), *(const bf16x8_t*)(a.dy + (base + p) * a.C + c));
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[(threadIdx.x * 3 + 0) * 8 + j] = sa[j];
+    red[(threadIdx.x * 3 + 1) * 8 + j] = sb[j];
+    red[(threadIdx.x * 3 + 2) * 8 + j] = sx[j];
+  }
+  reduce_to_global<3>(red, L, a.C, a.ws + (size_t)b * 3 * a.C);
+}
+
+// ---- backward sweep 2: dx = r * (k * du - A_g - xhat * B_g) (+ dextra); parameter-side gradients from chunk 0
+__global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(GnArgs a) {
+  __shared__ float s_A[256], s_B[256];
+  __shared__ float s_xa[MAXC], s_xb[MAXC], s_ua[MAXC], s_ub[MAXC];
+  const int b = blockIdx.y, p0 = blockIdx.x * a.pch;
+  const int p1 = min(a.HW, p0 + a.pch);
+  const float* wa = a.ws + (size_t)b * 3 * a.C;
+  const float* wb = wa + a.C;
+  const float* wx = wb + a.C;
+  bwd_constants(a, b, s_xa, s_xb, s_ua, s_ub);
+  const float inv_n = 1.0f / (float)(a.cg * a.HW);
+  for (int g = threadIdx.x; g < a.G; g += NT) {
+    float A = 0.f, Bv = 0.f;
+    for (int j = 0; j < a.cg; ++j) {
+      const int c = g * a.cg + j;
+      const float k = a.gamma[c] * (a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + c] : 1.f);
+      A += k * wa[c];
+      Bv += k * wb[c];
+    }
+    s_A[g] = A * inv_n;
+    s_B[g] = Bv * inv_n;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < a.C; c += NT) {
+      const float av = wa[c], bv = wb[c];
+      const float sc = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + c] : 1.f;
+      atomicAdd(a.dbeta + c, sc * av);
+      atomicAdd(a.dgamma + c, sc * bv);
+      if (a.dss) {
+        a.dss[(size_t)b * 2 * a.C + c] = a.gamma[c] * bv + a.beta[c] * av;
+        a.dss[(size_t)b * 2 * a.C + a.C + c] = av;
+      }
+      if (a.dpre) {
+        const int g = c / a.cg;
+        // sum over pixels of dx = r * (k * a_c - HW * A_g - B_g * sum xhat_c)
+        a.dpre[(size_t)b * a.C + c] = s_xa[c] * (sc * a.gamma[c] * av - (float)a.HW * s_A[g] - s_B[g] * wx[c]);
+      }
+    }
+  }
+  const Lanes L(a.C);
+  if (!L.active) return;
+  const int c = 8 * L.v;
+  float xa[8], xb[8], ua[8], ub[8], Ag[8], Bg[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    xa[j] = s_xa[c + j]; xb[j] = s_xb[c + j]; ua[j] = s_ua[c + j]; ub[j] = s_ub[c + j];
+    Ag[j] = s_A[(c + j) / a.cg]; Bg[j] = s_B[(c + j) / a.cg];
+  }
+  const size_t base = (size_t)b * a.HW;
+  auto emit = [&](const bf16x8_t& xr, const bf16x8_t& dr, int p) {
+    const size_t o = (base + p) * a.C + c;
+    float f[8], e[8];
+    if (a.dextra) dm_unpack8(*(const bf16x8_t*)(a.dextra + o), e);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xv = (float)xr[j];
+      const float xh = xa[j] * xv + xb[j];
+      const float du = a.act ? (float)dr[j] * dm_silu_grad(ua[j] * xv + ub[j]) : (float)dr[j];
+      // k * r = ua (u = ua * x + ub with ua = sc * gamma * r)
+      const float dxv = ua[j] * du - xa[j] * (Ag[j] + xh * Bg[j]);
+      f[j] = a.dextra ? dxv + e[j] : dxv;
+    }
+    const bf16x8_t ov = dm_pack8(f);
+    if (c < a.C1) *(bf16x8_t*)(a.dx1 + (base + p) * a.C1 + c) = ov;
+    else *(bf16x8_t*)(a.dx2 + (base + p) * a.C2 + (c - a.C1)) = ov;
+  };
+  int p = p0 + L.pl;
+  for (; p + L.PL < p1; p += 2 * L.PL) {
+    bf16x8_t x0 = load_x(a, base + p, c), x1 = load_x(a, base + p + L.PL, c);
+    bf16x8_t d0 = *(const bf16x8_t*)(a.dy + (base + p) * a.C + c);
+    bf16x8_t d1 = *(const bf16x8_t*)(a.dy + (base + p + L.PL) * a.C + c);
+    emit(x0, d0, p);
+    emit(x1, d1, p + L.PL);
+  }
+  for (; p < p1; p += L.PL) emit(load_x(a, base + p, c), *(const bf16x8_t*)(a.dy + (base + p) * a.C + c), p);
 }
 
 int check_desc(const dm_gn_desc* d, const char* who) {
@@ -264,31 +322,55 @@ int check_desc(const dm_gn_desc* d, const char* who) {
   DM_REQUIRE(d->B > 0 && d->HW > 0 && d->C1 > 0 && d->C2 >= 0 && d->G > 0, DM_ERR_SHAPE, "%s: empty tensor", who);
   DM_REQUIRE(d->C1 % 8 == 0 && d->C2 % 8 == 0, DM_ERR_SHAPE, "%s: channels (%d, %d) must be multiples of 8", who, d->C1, d->C2);
   DM_REQUIRE(C % d->G == 0, DM_ERR_SHAPE, "%s: %d channels not divisible into %d groups", who, C, d->G);
-  const int cg = C / d->G;
-  const int unit = cg / gcd_i(cg, 8) * 8;
-  DM_REQUIRE(C % unit == 0 && pick_slab(d->B, C, cg) > 0, DM_ERR_SHAPE, "%s: group size %d cannot be tiled by 16-byte vectors", who, cg);
+  DM_REQUIRE(C <= MAXC && d->G <= 256, DM_ERR_UNSUPPORTED, "%s: at most %d channels and 256 groups", who, MAXC);
+  DM_REQUIRE(d->B <= 65535, DM_ERR_UNSUPPORTED, "%s: batch %d > 65535", who, d->B);
   DM_REQUIRE(!(d->has_ss && d->has_pre), DM_ERR_ARG, "%s: scale_shift and pre_add are exclusive", who);
   return DM_OK;
 }
 
+// pixels per workgroup: aim at >= ~2048 workgroups, at least 4 unrolled iterations per thread
+int pick_chunk(int B, int HW, int C) {
+  const int PL = NT / (C / 8) > 0 ? NT / (C / 8) : 1;
+  int pch = 4 * PL;
+  while ((long)B * dm_cdiv(HW, pch) > 4096 && pch < HW) pch *= 2;
+  return pch;
+}
+
+void fill(GnArgs& a, const dm_gn_desc* d) {
+  a.B = d->B; a.HW = d->HW; a.C1 = d->C1; a.C2 = d->C2; a.C = d->C1 + d->C2; a.G = d->G; a.cg = a.C / a.G;
+  a.act = d->act; a.eps = d->eps;
+  a.pch = pick_chunk(a.B, a.HW, a.C);
+}
+
 }  // namespace
+
+extern "C" long dm_groupnorm_ws_floats(const dm_gn_desc* d) {
+  return d ? 3L * d->B * (d->C1 + d->C2) : 0;
+}
 
 extern "C" int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma,
                                     const float* beta, const float* scale_shift, const float* pre_add, void* y,
-                                    float* mean, float* rstd, void* stream) {
+                                    float* mean, float* rstd, float* ws, void* stream) {
   int rc = check_desc(d, "dm_groupnorm_act_fwd");
   if (rc) return rc;
-  DM_REQUIRE(x1 && gamma && beta && y && mean && rstd, DM_ERR_ARG, "dm_groupnorm_act_fwd: null argument");
+  DM_REQUIRE(x1 && gamma && beta && y && mean && rstd && ws, DM_ERR_ARG, "dm_groupnorm_act_fwd: null argument");
   DM_REQUIRE((d->C2 == 0) == (x2 == nullptr), DM_ERR_ARG, "dm_groupnorm_act_fwd: x2 and C2 disagree");
   DM_REQUIRE((d->has_ss != 0) == (scale_shift != nullptr) && (d->has_pre != 0) == (pre_add != nullptr), DM_ERR_ARG,
              "dm_groupnorm_act_fwd: scale_shift/pre_add pointers disagree with the descriptor");
-  DM_REQUIRE(((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y) % 16 == 0, DM_ERR_ARG, "dm_groupnorm_act_fwd: misaligned tensor");
+  DM_REQUIRE(((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y | (uintptr_t)ws) % 16 == 0, DM_ERR_ARG, "dm_groupnorm_act_fwd: misaligned tensor");
   GnArgs a = {};
   a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.pre = pre_add;
-  a.y = (bf16_t*)y; a.mean = mean; a.rstd = rstd;
-  a.B = d->B; a.HW = d->HW; a.C1 = d->C1; a.C2 = d->C2; a.C = d->C1 + d->C2; a.G = d->G; a.cg = a.C / a.G;
-  a.CS = pick_slab(a.B, a.C, a.cg); a.act = d->act; a.eps = d->eps;
-  hipLaunchKernelGGL(gn_fwd_kernel, dim3(a.C / a.CS, a.B), dim3(NT), 0, (hipStream_t)stream, a);
+  a.y = (bf16_t*)y; a.mean = mean; a.rstd = rstd; a.ws = ws;
+  fill(a, d);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * a.B * a.C, st) != hipSuccess) {
+    dm_set_error("dm_groupnorm_act_fwd: workspace memset failed");
+    return DM_ERR_LAUNCH;
+  }
+  dim3 grid(dm_cdiv(a.HW, a.pch), a.B);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(NT), 0, st, a);
+  DM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(NT), 0, st, a);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
@@ -296,27 +378,35 @@ extern "C" int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const v
 extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma,
                                     const float* beta, const float* scale_shift, const float* pre_add,
                                     const float* mean, const float* rstd, const void* dy, const void* dextra,
-                                    void* dx1, void* dx2, float* dgamma, float* dbeta,
-                                    float* dscale_shift, float* dpre_add, void* stream) {
+                                    void* dx1, void* dx2, float* dgamma, float* dbeta, float* dscale_shift,
+                                    float* dpre_add, float* ws, void* stream) {
   int rc = check_desc(d, "dm_groupnorm_act_bwd");
   if (rc) return rc;
-  DM_REQUIRE(x1 && gamma && beta && mean && rstd && dy && dx1 && dgamma && dbeta, DM_ERR_ARG,
+  DM_REQUIRE(x1 && gamma && beta && mean && rstd && dy && dx1 && dgamma && dbeta && ws, DM_ERR_ARG,
              "dm_groupnorm_act_bwd: null argument");
   DM_REQUIRE((d->C2 == 0) == (x2 == nullptr) && (d->C2 == 0) == (dx2 == nullptr), DM_ERR_ARG, "dm_groupnorm_act_bwd: x2/dx2 and C2 disagree");
   DM_REQUIRE((d->has_ss != 0) == (scale_shift != nullptr) && (d->has_ss != 0) == (dscale_shift != nullptr), DM_ERR_ARG,
              "dm_groupnorm_act_bwd: scale_shift pointers disagree with the descriptor");
   DM_REQUIRE((d->has_pre != 0) == (pre_add != nullptr) && (d->has_pre != 0) == (dpre_add != nullptr), DM_ERR_ARG,
              "dm_groupnorm_act_bwd: pre_add pointers disagree with the descriptor");
-  DM_REQUIRE(((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dy | (uintptr_t)dextra | (uintptr_t)dx1 | (uintptr_t)dx2) % 16 == 0,
+  DM_REQUIRE(((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dy | (uintptr_t)dextra | (uintptr_t)dx1 | (uintptr_t)dx2 | (uintptr_t)ws) % 16 == 0,
              DM_ERR_ARG, "dm_groupnorm_act_bwd: misaligned tensor");
   GnArgs a = {};
   a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.pre = pre_add;
-  a.mean_in = mean; a.rstd_in = rstd; a.dy = (const bf16_t*)dy; a.dextra = (const bf16_t*)dextra;
+  a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
+  a.dy = (const bf16_t*)dy; a.dextra = (const bf16_t*)dextra;
   a.dx1 = (bf16_t*)dx1; a.dx2 = (bf16_t*)dx2; a.dgamma = dgamma; a.dbeta = dbeta;
-  a.dss = dscale_shift; a.dpre = dpre_add;
-  a.B = d->B; a.HW = d->HW; a.C1 = d->C1; a.C2 = d->C2; a.C = d->C1 + d->C2; a.G = d->G; a.cg = a.C / a.G;
-  a.CS = pick_slab(a.B, a.C, a.cg); a.act = d->act; a.eps = d->eps;
-  hipLaunchKernelGGL(gn_bwd_kernel, dim3(a.C / a.CS, a.B), dim3(NT), 0, (hipStream_t)stream, a);
+  a.dss = dscale_shift; a.dpre = dpre_add; a.ws = ws;
+  fill(a, d);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, sizeof(float) * 3 * a.B * a.C, st) != hipSuccess) {
+    dm_set_error("dm_groupnorm_act_bwd: workspace memset failed");
+    return DM_ERR_LAUNCH;
+  }
+  dim3 grid(dm_cdiv(a.HW, a.pch), a.B);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(NT), 0, st, a);
+  DM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(NT), 0, st, a);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -120,6 +120,131 @@ __global__ __launch_bounds__(NT) void linear_bwd_w_kernel(const float* __restric
   }
 }
 
+// ---- grouped linear: P independent layers y_p = f(x) w_p^T + b_p sharing one input x [M][K] (the 17 emb_proj
+// layers of a UNet forward all read SiLU(embedding)); one launch for all of them, forward and backward.
+constexpr int MAX_GROUP = 32;
+struct LinearGroupItem {   // one per layer; the whole table travels by value in the kernel arguments
+  const float* w;   // [N][K]
+  const float* b;   // [N] or null
+  float* y;         // [M][N]
+  const float* dy;  // [M][N]
+  float* dw;        // [N][K] accumulates, or null
+  float* db;        // [N] accumulates, or null
+  int N;
+  int tile0;        // first 64-column tile / first 4-row tile of this layer in the launch grid
+};
+
+struct LinearGroup {
+  LinearGroupItem it[MAX_GROUP];
+  int P;
+};
+
+__device__ __forceinline__ int find_item(const LinearGroup& g, int tile) {
+  int p = 0;
+  while (p + 1 < g.P && g.it[p + 1].tile0 <= tile) ++p;
+  return p;
+}
+
+__global__ __launch_bounds__(NT) void linear_group_fwd_kernel(const float* __restrict__ x, const LinearGroup g, int M, int K,
+                                                              int act_in) {
+  extern __shared__ float lds[];
+  float* xs = lds;
+  float* ws = lds + LIN_ROWS * K;
+  const LinearGroupItem it = g.it[find_item(g, blockIdx.x)];
+  const int n0 = (blockIdx.x - it.tile0) * LIN_COLS, m0 = blockIdx.y * LIN_ROWS;
+  for (int i = threadIdx.x; i < LIN_ROWS * K; i += NT) {
+    const int r = i / K, k = i - r * K;
+    float v = (m0 + r < M) ? x[(size_t)(m0 + r) * K + k] : 0.f;
+    xs[i] = act_in ? dm_silu(v) : v;
+  }
+  for (int i = threadIdx.x; i < LIN_COLS * K; i += NT) {
+    const int c = i / K, k = i - c * K;
+    ws[c * (K + 1) + k] = (n0 + c < it.N) ? it.w[(size_t)(n0 + c) * K + k] : 0.f;
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < K; ++k) {
+    const float wv = ws[c * (K + 1) + k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += xs[(rg * 4 + r) * K + k] * wv;
+  }
+  if (n0 + c < it.N) {
+    const float bv = it.b ? it.b[n0 + c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + rg * 4 + r;
+      if (m < M) it.y[(size_t)m * it.N + n0 + c] = acc[r] + bv;
+    }
+  }
+}
+
+// dx[m][k] += f'(x[m][k]) * sum_n dy_p[m][n] w_p[n][k]; grid (k tiles, m tiles, layers), dx zeroed by the caller
+__global__ __launch_bounds__(NT) void linear_group_bwd_x_kernel(const float* __restrict__ x, const LinearGroup g,
+                                                                float* __restrict__ dx, int M, int K, int act_in) {
+  __shared__ float sdy[BX_ROWS][BX_CHUNK];
+  __shared__ float sw[BX_CHUNK][BX_COLS];
+  const LinearGroupItem it = g.it[blockIdx.z];
+  const int N = it.N;
+  const int k0 = blockIdx.x * BX_COLS, m0 = blockIdx.y * BX_ROWS;
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int n0 = 0; n0 < N; n0 += BX_CHUNK) {
+    __syncthreads();
+    if (threadIdx.x < BX_ROWS * BX_CHUNK) {
+      const int rr = threadIdx.x / BX_CHUNK, nn = threadIdx.x % BX_CHUNK;
+      sdy[rr][nn] = (m0 + rr < M && n0 + nn < N) ? it.dy[(size_t)(m0 + rr) * N + n0 + nn] : 0.f;
+    }
+    for (int i = threadIdx.x; i < BX_CHUNK * BX_COLS; i += NT) {
+      const int nn = i / BX_COLS, cc = i % BX_COLS;
+      sw[nn][cc] = (n0 + nn < N && k0 + cc < K) ? it.w[(size_t)(n0 + nn) * K + k0 + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nn = 0; nn < BX_CHUNK; ++nn) acc += sdy[r][nn] * sw[nn][c];
+  }
+  const int m = m0 + r, k = k0 + c;
+  if (m < M && k < K) {
+    if (act_in) acc *= dm_silu_grad(x[(size_t)m * K + k]);
+    atomicAdd(dx + (size_t)m * K + k, acc);
+  }
+}
+
+// dw_p[n][k] += sum_m dy_p[m][n] f(x[m][k]); db_p[n] += sum_m dy_p[m][n]; grid (k tiles, 4-row tiles over all layers)
+__global__ __launch_bounds__(NT) void linear_group_bwd_w_kernel(const float* __restrict__ x, const LinearGroup g, int M, int K,
+                                                                int act_in) {
+  __shared__ float sdy[BW_MAXM][BW_ROWS];
+  const LinearGroupItem it = g.it[find_item(g, blockIdx.y)];
+  const int N = it.N;
+  const int k0 = blockIdx.x * BW_COLS, n0 = (blockIdx.y - it.tile0) * BW_ROWS;
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int k = k0 + c, n = n0 + r;
+  float acc = 0.f, bsum = 0.f;
+  for (int mb = 0; mb < M; mb += BW_MAXM) {
+    const int mc = min(BW_MAXM, M - mb);
+    __syncthreads();
+    for (int i = threadIdx.x; i < mc * BW_ROWS; i += NT) {
+      const int mm = i / BW_ROWS, rr = i % BW_ROWS;
+      sdy[mm][rr] = (n0 + rr < N) ? it.dy[(size_t)(mb + mm) * N + n0 + rr] : 0.f;
+    }
+    __syncthreads();
+    if (k < K) {
+#pragma unroll 4
+      for (int mm = 0; mm < mc; ++mm) {
+        float xv = x[(size_t)(mb + mm) * K + k];
+        if (act_in) xv = dm_silu(xv);
+        acc += sdy[mm][r] * xv;
+      }
+    }
+    if (it.db && blockIdx.x == 0 && c == 0)
+      for (int mm = 0; mm < mc; ++mm) bsum += sdy[mm][r];
+  }
+  if (n < N) {
+    if (it.dw && k < K) it.dw[(size_t)n * K + k] += acc;
+    if (it.db && blockIdx.x == 0 && c == 0) it.db[n] += bsum;
+  }
+}
+
 // ---- class embedding
 __device__ __forceinline__ int class_index(const int64_t* cls, const float* mask, int uncond, int b) {
   if (!cls) return uncond;
@@ -278,6 +403,59 @@ extern "C" int dm_linear_bwd(const float* x, const float* w, const float* dy, fl
                        x, dy, dw, dbias, M, K, N, act_in);
     DM_CHECK_LAUNCH();
   }
+  return DM_OK;
+}
+
+static int fill_group(LinearGroup& g, const dm_linear_item* items, int P, int tile_cols, int* total) {
+  DM_REQUIRE(items && P > 0 && P <= MAX_GROUP, DM_ERR_ARG, "dm_linear_group: 1..%d layers per call, got %d", MAX_GROUP, P);
+  int t = 0;
+  for (int p = 0; p < P; ++p) {
+    DM_REQUIRE(items[p].w && items[p].N > 0, DM_ERR_ARG, "dm_linear_group: layer %d has no weight", p);
+    g.it[p].w = items[p].w; g.it[p].b = items[p].b; g.it[p].y = items[p].y; g.it[p].dy = items[p].dy;
+    g.it[p].dw = items[p].dw; g.it[p].db = items[p].db; g.it[p].N = items[p].N; g.it[p].tile0 = t;
+    t += dm_cdiv(items[p].N, tile_cols);
+  }
+  g.P = P;
+  *total = t;
+  return DM_OK;
+}
+
+extern "C" int dm_linear_group_fwd(const float* x, const dm_linear_item* items, int P, int M, int K, int act_in,
+                                   void* stream) {
+  DM_REQUIRE(x && M > 0 && K > 0, DM_ERR_ARG, "dm_linear_group_fwd: bad argument");
+  LinearGroup g;
+  int tiles = 0;
+  int rc = fill_group(g, items, P, LIN_COLS, &tiles);
+  if (rc) return rc;
+  for (int p = 0; p < P; ++p) DM_REQUIRE(items[p].y, DM_ERR_ARG, "dm_linear_group_fwd: layer %d has no output", p);
+  const int lds = (LIN_ROWS * K + LIN_COLS * (K + 1)) * 4;
+  DM_REQUIRE(lds <= 65536, DM_ERR_UNSUPPORTED, "dm_linear_group_fwd: K=%d too large", K);
+  hipLaunchKernelGGL(linear_group_fwd_kernel, dim3(tiles, dm_cdiv(M, LIN_ROWS)), dim3(NT), lds, (hipStream_t)stream, x, g, M, K,
+                     act_in);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_linear_group_bwd(const float* x, const dm_linear_item* items, int P, float* dx, int M, int K, int act_in,
+                                   void* stream) {
+  DM_REQUIRE(x && M > 0 && K > 0, DM_ERR_ARG, "dm_linear_group_bwd: bad argument");
+  LinearGroup g;
+  int tiles = 0;
+  int rc = fill_group(g, items, P, BW_ROWS, &tiles);
+  if (rc) return rc;
+  for (int p = 0; p < P; ++p) DM_REQUIRE(items[p].dy, DM_ERR_ARG, "dm_linear_group_bwd: layer %d has no output gradient", p);
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) {
+    if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * K, st) != hipSuccess) {
+      dm_set_error("dm_linear_group_bwd: memset failed");
+      return DM_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(linear_group_bwd_x_kernel, dim3(dm_cdiv(K, BX_COLS), dm_cdiv(M, BX_ROWS), P), dim3(NT), 0, st, x, g, dx, M,
+                       K, act_in);
+    DM_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(linear_group_bwd_w_kernel, dim3(dm_cdiv(K, BW_COLS), tiles), dim3(NT), 0, st, x, g, M, K, act_in);
+  DM_CHECK_LAUNCH();
   return DM_OK;
 }
 

@@ -30,6 +30,11 @@ class GnDesc(ctypes.Structure):
                 ("act", c_int), ("has_ss", c_int), ("has_pre", c_int)]
 
 
+class LinearItem(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("y", c_void_p), ("dy", c_void_p), ("dw", c_void_p),
+                ("db", c_void_p), ("N", c_int)]
+
+
 P = c_void_p
 _SIGNATURES = {
     "dm_abi_version": (c_int, []),
@@ -42,13 +47,16 @@ _SIGNATURES = {
     "dm_out_conv_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dm_out_conv_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dm_edge_conv_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "dm_groupnorm_act_fwd": (c_int, [ctypes.POINTER(GnDesc), P, P, P, P, P, P, P, P, P, P]),
-    "dm_groupnorm_act_bwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 17),
+    "dm_groupnorm_ws_floats": (c_long, [ctypes.POINTER(GnDesc)]),
+    "dm_groupnorm_act_fwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 11),
+    "dm_groupnorm_act_bwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 18),
     "dm_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "dm_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "dm_timestep_embed": (c_int, [P, P, P, c_int, c_int, P]),
     "dm_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dm_linear_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dm_linear_group_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "dm_linear_group_bwd": (c_int, [P, P, c_int, P, c_int, c_int, c_int, P]),
     "dm_class_embed_add": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "dm_class_embed_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "dm_upsample2x_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -9,7 +9,7 @@ import ctypes
 import torch
 from torch.autograd import Function
 
-from . import ConvDesc, GnDesc, check, lib
+from . import ConvDesc, GnDesc, LinearItem, check, lib
 
 BF16 = torch.bfloat16
 CL = torch.channels_last
@@ -224,9 +224,10 @@ class _GroupNormActFn(Function):
         mean = torch.empty((B, G), dtype=torch.float32, device=x1.device)
         rstd = torch.empty((B, G), dtype=torch.float32, device=x1.device)
         d = GnDesc(B, H * W, C1, C2, G, eps, int(act), int(ss32 is not None), int(pre32 is not None))
+        ws = torch.empty(3 * B * C, dtype=torch.float32, device=x1.device)
         check(lib.dm_groupnorm_act_fwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
                                        _p(ss32), _p(pre32), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                       _stream()))
+                                       ws.data_ptr(), _stream()))
         ctx.save_for_backward(x1, x2, g32, b32, ss32, pre32, mean, rstd)
         ctx.params = (gamma, beta)
         ctx.cfg = (d, B, C1, C2, H, W)
@@ -251,10 +252,11 @@ class _GroupNormActFn(Function):
         dss = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if ss32 is not None else None
         dpre = torch.empty((B, C), dtype=torch.float32, device=dev) if pre32 is not None else None
         st = _stream()
+        ws = torch.empty(3 * B * C, dtype=torch.float32, device=dev)
         check(lib.dm_groupnorm_act_bwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
                                        _p(ss32), _p(pre32), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), None,
                                        dx1.data_ptr(), _p(dx2), dg.data_ptr(), db_.data_ptr(), _p(dss),
-                                       _p(dpre), st))
+                                       _p(dpre), ws.data_ptr(), st))
         if direct:
             _grad_done(ctx.params[0])
             _grad_done(ctx.params[1])
@@ -345,6 +347,73 @@ class _LinearFn(Function):
 
 def linear(x, weight, bias, act_in=False):
     return _LinearFn.apply(x, weight, bias, act_in)
+
+
+class _LinearGroupFn(Function):
+    """P fp32 linears sharing one input, one launch each way: y_p = f(x) @ w_p.T + b_p.
+    apply(x, act_in, w_0, b_0, w_1, b_1, ...) -> (y_0, y_1, ...)"""
+
+    @staticmethod
+    def forward(ctx, x, act_in, *wb):
+        _require_device(x, "linear_group")
+        x32 = f32c(x)
+        M, K = x32.shape
+        ws, bs = wb[0::2], wb[1::2]
+        P = len(ws)
+        w32 = [f32c(w.detach()) for w in ws]
+        b32 = [f32c(b.detach()) if b is not None else None for b in bs]
+        ys = [torch.empty((M, w.shape[0]), dtype=torch.float32, device=x.device) for w in w32]
+        items = (LinearItem * P)()
+        for i in range(P):
+            items[i].w, items[i].b, items[i].y, items[i].N = w32[i].data_ptr(), _p(b32[i]), ys[i].data_ptr(), w32[i].shape[0]
+        check(lib.dm_linear_group_fwd(x32.data_ptr(), items, P, M, K, int(act_in), _stream()))
+        ctx.save_for_backward(x32, *w32)
+        ctx.params = (ws, bs)
+        ctx.cfg = (M, K, int(act_in))
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x32, *w32 = ctx.saved_tensors
+        ws, bs = ctx.params
+        M, K, act_in = ctx.cfg
+        P = len(w32)
+        dev = x32.device
+        dx = torch.empty((M, K), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        items = (LinearItem * P)()
+        keep, grads, sinks = [], [None] * (2 * P), []
+        for i in range(P):
+            N = w32[i].shape[0]
+            dy = f32c(dys[i]) if dys[i] is not None else torch.zeros((M, N), dtype=torch.float32, device=dev)
+            keep.append(dy)
+            wsink = _grad_sink(ws[i]) if ctx.needs_input_grad[2 + 2 * i] else None
+            dw = wsink if wsink is not None else (torch.zeros((N, K), dtype=torch.float32, device=dev)
+                                                  if ctx.needs_input_grad[2 + 2 * i] else None)
+            bsink = db = None
+            if bs[i] is not None and ctx.needs_input_grad[3 + 2 * i]:
+                bsink = _grad_sink(bs[i])
+                db = bsink if bsink is not None else torch.zeros((N,), dtype=torch.float32, device=dev)
+            items[i].w, items[i].dy, items[i].dw, items[i].db, items[i].N = w32[i].data_ptr(), dy.data_ptr(), _p(dw), _p(db), N
+            if wsink is None:
+                grads[2 * i] = dw
+            else:
+                sinks.append(ws[i])
+            if bsink is None:
+                grads[2 * i + 1] = db
+            else:
+                sinks.append(bs[i])
+        check(lib.dm_linear_group_bwd(x32.data_ptr(), items, P, _p(dx), M, K, act_in, _stream()))
+        for prm in sinks:
+            _grad_done(prm)
+        return (dx, None) + tuple(grads)
+
+
+def linear_group(x, layers, act_in=False):
+    """layers: sequence of (weight, bias) with a common input width; returns the list of outputs."""
+    flat = []
+    for w, b in layers:
+        flat += [w, b]
+    return list(_LinearGroupFn.apply(x, act_in, *flat))
 
 
 def timestep_embed(t, freq):

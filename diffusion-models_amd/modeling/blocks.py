@@ -16,6 +16,25 @@ from modeling.attention import Attention2D
 from modeling.layers import Conv2d, EmbLinear, GroupNorm
 
 
+class ProjectedEmbeddings:
+    """All per-block embedding projections of one forward pass, computed in ONE grouped launch by the owner of the
+    blocks (every emb_proj reads the same SiLU(embedding)), handed to the blocks in place of the raw embedding."""
+
+    MAX_GROUP = 32
+
+    def __init__(self, embedding: torch.Tensor, blocks):
+        self.raw = embedding
+        blocks = [b for b in blocks if b.emb_proj is not None and is_silu(b.nonlinearity)]
+        self._proj = {}
+        for i in range(0, len(blocks), self.MAX_GROUP):
+            chunk = blocks[i:i + self.MAX_GROUP]
+            outs = ops.linear_group(embedding, [(b.emb_proj.weight, b.emb_proj.bias) for b in chunk], act_in=True)
+            self._proj.update({id(b): o for b, o in zip(chunk, outs)})
+
+    def for_block(self, block):
+        return self._proj.get(id(block))
+
+
 class ConvBlock(nn.Module):
     """GN-act-conv3x3, embedding mix, GN-act-(dropout)-conv3x3, plus (projected) residual
     (reference: modeling/blocks.py:10-75). `skip`, when given, is a second input concatenated after `x` on the
@@ -65,7 +84,13 @@ class ConvBlock(nn.Module):
         mix = {}
         if self.emb_proj is not None:
             assert embedding is not None
-            if is_silu(self.nonlinearity):
+            e = None
+            if isinstance(embedding, ProjectedEmbeddings):
+                e = embedding.for_block(self)
+                embedding = embedding.raw
+            if e is not None:
+                pass
+            elif is_silu(self.nonlinearity):
                 e = self.emb_proj(embedding, act_in=True)
             else:
                 e = self.emb_proj(self.nonlinearity(embedding))

@@ -10,7 +10,7 @@ from torch import nn
 
 from dm_hip import ops
 from modeling.activation import get_activation, is_silu
-from modeling.blocks import MidBlock, get_down_block, get_up_block
+from modeling.blocks import ConvBlock, MidBlock, ProjectedEmbeddings, get_down_block, get_up_block
 from modeling.embeddings import MLPEmbedding, PeriodicEncoding
 from modeling.layers import GroupNorm
 from modeling.predictor import GuidedPredictor
@@ -93,6 +93,7 @@ class UNet(nn.Module, GuidedPredictor):
         self.out_norm = GroupNorm(norm_groups, widths[0])
         self.out_act = get_activation(activation)
         self.out_conv = _EdgeConv(widths[0], out_channels, image_side="out")
+        self._conv_blocks = [m for m in self.modules() if isinstance(m, ConvBlock)]  # plain list: not registered
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, cls: Optional[torch.Tensor] = None,
                 uncond_mask: Optional[torch.Tensor] = None):
@@ -101,6 +102,9 @@ class UNet(nn.Module, GuidedPredictor):
             # masked / missing labels map to the padding row, which is zero and never receives gradient
             embedding = ops.class_embed_add(embedding, self.class_embedding.weight, cls,
                                             uncond_mask if cls is not None else None, self._uncond_idx)
+
+        # every ConvBlock projects the same SiLU(embedding): do all projections in one grouped launch
+        embedding = ProjectedEmbeddings(embedding, self._conv_blocks)
 
         h = self.in_conv(x)
         skips = (h,)

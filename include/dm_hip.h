@@ -109,15 +109,17 @@ typedef struct dm_gn_desc {
   int has_pre; /* pre_add fp32 [B][C] present */
 } dm_gn_desc;
 
+/* fp32 elements of the caller-provided workspace `ws` both calls need (3*B*C); its contents are scratch */
+long dm_groupnorm_ws_floats(const dm_gn_desc* d);
 int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma, const float* beta,
-                         const float* scale_shift, const float* pre_add, void* y, float* mean, float* rstd,
+                         const float* scale_shift, const float* pre_add, void* y, float* mean, float* rstd, float* ws,
                          void* stream);
 /* dx1|dx2 bf16 (= GN backward + dextra, dextra optional bf16 [B][HW][C]); dgamma/dbeta fp32 [C] ACCUMULATE
  * (atomics); dscale_shift fp32 [B][2C] and dpre_add fp32 [B][C] are written when present */
 int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma, const float* beta,
                          const float* scale_shift, const float* pre_add, const float* mean, const float* rstd,
                          const void* dy, const void* dextra, void* dx1, void* dx2, float* dgamma, float* dbeta,
-                         float* dscale_shift, float* dpre_add, void* stream);
+                         float* dscale_shift, float* dpre_add, float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Spatial self-attention core. Replaces F.scaled_dot_product_attention and the view/permute/contiguous
@@ -140,6 +142,23 @@ int dm_linear_fwd(const float* x, const float* w, const float* bias, float* y, i
  * dbias[n] += sum_m dy[m][n]  (dw/dbias may be null) */
 int dm_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias, int M, int K,
                   int N, int act_in, void* stream);
+/* P <= 32 layers sharing one input x [M][K] in ONE launch (the per-block emb_proj layers, modeling/blocks.py:56-57,
+ * all read SiLU(embedding)). `items` is a HOST array; the pointers inside are device pointers.
+ * forward:  y_p[m][n] = sum_k f(x[m][k]) w_p[n][k] + b_p[n]
+ * backward: dx[m][k] = f'(x[m][k]) * sum_p sum_n dy_p[m][n] w_p[n][k]  (dx may be null);
+ *           dw_p += dy_p^T f(x), db_p += column sums of dy_p  (accumulate; either may be null) */
+typedef struct dm_linear_item {
+  const float* w;   /* [N][K] */
+  const float* b;   /* [N] or null */
+  float* y;         /* [M][N]   (forward) */
+  const float* dy;  /* [M][N]   (backward) */
+  float* dw;        /* [N][K]   (backward, accumulates) */
+  float* db;        /* [N]      (backward, accumulates) */
+  int N;
+} dm_linear_item;
+int dm_linear_group_fwd(const float* x, const dm_linear_item* items, int P, int M, int K, int act_in, void* stream);
+int dm_linear_group_bwd(const float* x, const dm_linear_item* items, int P, float* dx, int M, int K, int act_in,
+                        void* stream);
 /* emb[b][:] += table[idx(b)][:], idx(b) = (cls == null || mask[b] != 0) ? uncond_idx : cls[b] */
 int dm_class_embed_add(float* emb, const float* table, const int64_t* cls, const float* mask, int uncond_idx, int B,
                        int E, void* stream);
