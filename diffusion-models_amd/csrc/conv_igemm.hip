@@ -237,6 +237,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(ConvArgs a) {
 
 }  // namespace
 
+int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                      const void* res, void* y, hipStream_t st);
+extern int g_dm_use_patch_kernel;
+
 extern "C" int dm_conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const void* w,
                                const float* bias, const void* res, void* y, void* stream) {
   DM_REQUIRE(d && x1 && w && y, DM_ERR_ARG, "dm_conv2d_igemm: null argument");
@@ -263,6 +267,14 @@ extern "C" int dm_conv2d_igemm(const dm_conv_desc* d, const void* x1, const void
   const long wbytes = (long)d->Cout * d->KH * d->KW * Cin * 2;
   DM_REQUIRE(npix_src * d->C1 * 2 < 0x7fffffffL && npix_src * d->C2 * 2 < 0x7fffffffL && wbytes < 0x7fffffffL && M < 0x7fffffffL,
              DM_ERR_UNSUPPORTED, "dm_conv2d_igemm: tensor larger than 2 GiB");
+
+  DM_REQUIRE(((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)res | (uintptr_t)y) % 16 == 0,
+             DM_ERR_ARG, "dm_conv2d_igemm: pointers must be 16-byte aligned");
+  // 3x3 stride-1 convs (and their data gradients) go to the LDS-staged-patch kernel when the shape allows
+  if (g_dm_use_patch_kernel && dm_conv_patch_try(d, x1, x2, w, bias, res, y, (hipStream_t)stream) == DM_OK) {
+    DM_CHECK_LAUNCH();
+    return DM_OK;
+  }
 
   ConvArgs a;
   a.x1 = x1; a.x2 = x2; a.w = w; a.bias = bias; a.res = res; a.y = y;

@@ -1,0 +1,317 @@
+// 3x3 stride-1 convolution (forward, and data gradient of such a conv) as implicit GEMM on bf16 MFMA with
+// LDS-STAGED INPUT PATCHES.
+//
+// Why a second conv kernel: a CU moves only ~70 GB/s (~29 B/clk) from L2 into LDS, and a 128x128x64 GEMM step
+// needs 32 KB of operands for 512 MFMA-cycles, so a plain gathered implicit GEMM tops out near 45 % of the MFMA
+// rate. A 3x3 conv re-reads every input pixel for 9 taps; here a tile's input pixels (with their halo) are brought
+// into LDS ONCE per 64-channel chunk and all 9 taps multiply shifted views of that patch, and the tile is 256
+// pixels tall so each weight byte is used twice as often. Operand traffic per MFMA drops ~3x.
+//
+// Tile: 256 output pixels (whole image rows, possibly several small images) x BN output channels, 8 waves (4x2),
+// each wave 64 x BN/2. Per 64-channel chunk: patch [rows+halo][W+2][64] (zero halo through the buffer range check),
+// double buffered; weights [BN][64] per tap through a 3-deep ring. All loads are buffer_load ... lds with counted
+// vmcnt waits (loads stay in flight across the per-tap barrier); 16-byte chunks are XOR-swizzled by pixel / row
+// index on the source side so fragment reads (ds_read_b128) are conflict free.
+//
+// Patch geometry. Output pixels of a tile are TR consecutive rows of the "stacked" image (all B*H rows one after the
+// other), so they are one contiguous range of the NHWC tensor. In LDS every image that the tile touches gets its own
+// zero row above and below, so a tap shift never crosses from one image into the next:
+//   patch row of stacked row r = (r - R0) + 1 + 2 * (image(r) - image(R0)),   patch col of column x = x + 1
+// and tap (kh, kw) reads patch pixel (row - 1 + kh, col - 1 + kw): a lane-independent offset.
+#include "dm_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int BM = 256;
+constexpr int BK = 64;
+constexpr int NTHREADS = 512;
+
+struct PatchArgs {
+  const void* x1;
+  const void* x2;
+  const void* w;
+  const float* bias;
+  const void* res;
+  void* y;
+  int C1, C2, Cin, Cout;
+  int B, H, W, Hs, Ws, ups, transposed;
+  int TR, PW;  // rows per tile, patch width (W + 2)
+  int M, n_mtiles, n_ntiles;
+  unsigned x1_bytes, x2_bytes, w_bytes;
+};
+
+template <int BN, int NP>
+struct Lay {
+  static constexpr int PIX_CAP = NP * NTHREADS / 8;  // patch pixels per buffer
+  static constexpr int A_BYTES = PIX_CAP * BK * 2;
+  static constexpr int B_BYTES = BN * BK * 2;
+  static constexpr int A0 = 0, A1 = A_BYTES, B0 = 2 * A_BYTES;
+  static constexpr int STAGE_TOTAL = 2 * A_BYTES + 3 * B_BYTES;
+  static constexpr int EP_PITCH = BN + 4;
+  static constexpr int EP_BYTES = BM * EP_PITCH * 4;
+  static constexpr int TOTAL = STAGE_TOTAL > EP_BYTES ? STAGE_TOTAL : EP_BYTES;
+  static constexpr int B_PIECES = BN * 8 / NTHREADS;  // 16-byte pieces of a weight stage per thread
+};
+
+// one A-patch piece is issued in tap steps 0..NP-1 of every chunk; loads younger than the weight stage a step waits for
+template <int BP, int NP>
+__device__ __forceinline__ constexpr int younger_loads(int tap) {
+  const int t1 = (tap + 8) % 9, t2 = (tap + 7) % 9;
+  return BP + (t1 < NP ? 1 : 0) + (t2 < NP ? 1 : 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BN, int NP>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
+  using L = Lay<BN, NP>;
+  constexpr int WN = BN / 2, NJ = WN / 16, MI = 4, BP = L::B_PIECES;
+  __shared__ __attribute__((aligned(16))) char smem[L::TOTAL];
+
+  int mt, nt;
+  dm_xcd_tile(blockIdx.x, a.n_ntiles, mt, nt);
+  if (mt >= a.n_mtiles) return;
+  const int n0 = nt * BN;
+  const int R0 = mt * a.TR;            // first stacked row of the tile
+  const int b0 = R0 / a.H, y0 = R0 - b0 * a.H;
+  const int nrow0 = min(a.H - y0, a.TR);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x1), 0, a.x1_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x2 ? a.x2 : a.x1), 0,
+                                                                 a.x2 ? a.x2_bytes : 0u, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+
+  // ---- patch staging: this thread's NP pieces = fixed 16-byte slot (tid & 7) of patch pixels (tid >> 3) + 64 * i
+  const int spix = tid >> 3;
+  const int chunkA = (tid & 7) ^ (spix & 7);   // (pixel & 7) is the same for all i
+  int gsrc[NP];                                // source pixel index, -1: zero
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pp = spix + 64 * i;
+    const int pr = pp / a.PW, pc = pp - pr * a.PW;
+    int k, local, ystart;
+    if (pr < nrow0 + 2) { k = 0; local = pr; ystart = y0; }
+    else {
+      const int q = pr - (nrow0 + 2);
+      k = 1 + q / (a.H + 2);
+      local = q - (k - 1) * (a.H + 2);
+      ystart = 0;
+    }
+    const int yin = ystart - 1 + local, xin = pc - 1, b = b0 + k;
+    const bool ok = xin >= 0 && xin < a.W && yin >= 0 && yin < a.H && b < a.B;
+    gsrc[i] = ok ? ((b * a.Hs + (yin >> a.ups)) * a.Ws + (xin >> a.ups)) : -1;
+  }
+  unsigned wrow[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int n = n0 + (tid >> 3) + 64 * i;
+    const int chunkB = (tid & 7) ^ ((tid >> 3) & 7);
+    wrow[i] = (n < a.Cout) ? (unsigned)(n * 9 * a.Cin * 2 + chunkB * 16) : DM_OOB;
+  }
+
+  auto issue_A_piece = [&](int i, int cc, int buf) {   // piece i of the patch for channel chunk cc
+    unsigned off = DM_OOB;
+    const bool second = cc >= a.C1;
+    if (cc < a.Cin && gsrc[i] >= 0) {
+      const int csrc = second ? a.C2 : a.C1;
+      off = (unsigned)(gsrc[i] * csrc * 2 + (second ? cc - a.C1 : cc) * 2 + chunkA * 16);
+    }
+    char* dst = smem + (buf ? L::A1 : L::A0) + (wave * 64 + NTHREADS * i) * 16;
+    if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, DM_LDS(dst), 16, off, 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, DM_LDS(dst), 16, off, 0, 0, 0);
+  };
+  auto issue_B = [&](int tap, int cc, int stage) {     // weights of (tap, chunk cc); cc >= Cin: nothing (zeros)
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      unsigned off = (wrow[i] == DM_OOB || cc >= a.Cin) ? DM_OOB : wrow[i] + (unsigned)((tap * a.Cin + cc) * 2);
+      char* dst = smem + L::B0 + stage * L::B_BYTES + (wave * 64 + NTHREADS * i) * 16;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, DM_LDS(dst), 16, off, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment geometry
+  const int frow = lane & 15, fq = lane >> 4;
+  int pA[MI];       // patch pixel of this lane's row of M-tile i at tap offset 0
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int lp = wm * 64 + i * 16 + frow;
+    const int ry = lp / a.W, x = lp - ry * a.W;
+    const int r = R0 + ry;
+    if (ry < a.TR && r < a.B * a.H) pA[i] = (ry + 2 * (r / a.H - b0)) * a.PW + x;
+    else pA[i] = 0;  // rows outside the tile compute garbage that is never stored
+  }
+  int b_off[NJ][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int row = wn * WN + j * 16 + frow;
+      b_off[j][kk] = row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4);
+    }
+
+  f32x4_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: patch of chunk 0, weights of steps 0 and 1
+#pragma unroll
+  for (int i = 0; i < NP; ++i) issue_A_piece(i, 0, 0);
+  issue_B(0, 0, 0);
+  issue_B(1, 0, 1);
+
+  const int nchunks = a.Cin / BK;
+  for (int c = 0; c < nchunks; ++c) {
+    const int cc = c * BK;
+    const char* abuf = smem + ((c & 1) ? L::A1 : L::A0);
+    // keep the 72 per-tap fragment addresses from being hoisted out of this loop into registers
+    int pw = a.PW;
+    asm volatile("" : "+s"(pw));
+    auto step = [&](auto tap_c) {
+      constexpr int tap = decltype(tap_c)::value;
+      // weights of this step (and everything older, i.e. this chunk's patch) have landed for this wave ...
+      wait_vmcnt<younger_loads<BP, NP>(tap)>();
+      // ... and for every wave; every wave has also finished the previous step, whose weight stage is refilled next
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // weights two steps ahead, and one piece of the next chunk's patch
+      {
+        const int t2 = (tap + 2) % 9;
+        issue_B(t2, tap + 2 >= 9 ? cc + BK : cc, (tap + 2) % 3);
+        if (tap < NP) issue_A_piece(tap, cc + BK, (c + 1) & 1);
+      }
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const int toff = a.transposed ? ((2 - kh) * pw + (2 - kw)) : (kh * pw + kw);
+      const char* bbuf = smem + L::B0 + (tap % 3) * L::B_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8_t af[MI], bfr[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int p = pA[i] + toff;
+          af[i] = *(const bf16x8_t*)(abuf + (p << 7) + ((((kk * 4 + fq) ^ p) & 7) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[j] = *(const bf16x8_t*)(bbuf + b_off[j][kk]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+    step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});
+    step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{});
+  }
+
+  // ---- epilogue (the trailing dummy loads must have landed before LDS is reused)
+  wait_vmcnt<0>();
+  __syncthreads();
+  float* ep = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ep[(wm * 64 + i * 16 + fq * 4 + r) * L::EP_PITCH + wn * WN + j * 16 + frow] = acc[i][j][r];
+  __syncthreads();
+  constexpr int CPR = BN / 8;
+  bf16_t* y = (bf16_t*)a.y;
+  const bf16_t* res = (const bf16_t*)a.res;
+  const int m0 = R0 * a.W;              // the tile's output pixels are contiguous in memory
+  const int rows_valid = min(a.TR * a.W, a.M - m0);
+#pragma unroll 2
+  for (int it = 0; it < (BM * CPR) / NTHREADS; ++it) {
+    const int item = tid + NTHREADS * it;
+    const int row = item / CPR, cch = item - row * CPR;
+    const int n = n0 + cch * 8;
+    if (row < rows_valid && n < a.Cout) {
+      const float* src = ep + row * L::EP_PITCH + cch * 8;
+      const f32x4_t v0 = *(const f32x4_t*)src, v1 = *(const f32x4_t*)(src + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      if (a.bias) {
+        const f32x4_t c0 = *(const f32x4_t*)(a.bias + n), c1 = *(const f32x4_t*)(a.bias + n + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += c0[j]; v[4 + j] += c1[j]; }
+      }
+      const size_t o = (size_t)(m0 + row) * a.Cout + n;
+      if (res) {
+        const bf16x8_t rv = *(const bf16x8_t*)(res + o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+      }
+      *(bf16x8_t*)(y + o) = dm_pack8(v);
+    }
+  }
+}
+
+// most images a run of tr stacked rows of H-row images can touch, given that runs start at multiples of tr
+int images_touched(int tr, int H) {
+  if (tr <= H && H % tr == 0) return 1;
+  if (tr > H && tr % H == 0) return tr / H;
+  return (tr + H - 2) / H + 1;
+}
+
+// rows per tile such that the tile has <= 256 pixels and its patch (own zero rows per image) fits `cap` pixels
+int pick_rows(int H, int W, int cap) {
+  for (int tr = BM / W; tr > 0; --tr)
+    if ((tr + 2 * images_touched(tr, H)) * (W + 2) <= cap) return tr;
+  return 0;
+}
+
+}  // namespace
+
+// Returns DM_OK if handled, DM_ERR_UNSUPPORTED (without setting an error) when the shape is not covered and the
+// caller should use the gathered implicit-GEMM kernel.
+int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                      const void* res, void* y, hipStream_t st) {
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return DM_ERR_UNSUPPORTED;
+  const int H = d->Ho, W = d->Wo;
+  if (W > BM || d->Cout % 8) return DM_ERR_UNSUPPORTED;
+  const int Cin = d->C1 + d->C2;
+  if (Cin % BK || d->C1 % BK) return DM_ERR_UNSUPPORTED;
+  // narrow outputs on small images: 64-column tiles keep every CU busy
+  const long M = (long)d->B * H * W;
+  const bool bn64 = d->Cout <= 64 || (M / BM) * dm_cdiv(d->Cout, 128) < 200;
+  const int cap = bn64 ? Lay<64, 7>::PIX_CAP : Lay<128, 6>::PIX_CAP;
+  const int TR = pick_rows(H, W, cap);
+  if (TR <= 0 || TR * W < BM / 2) return DM_ERR_UNSUPPORTED;   // too ragged to be worth it
+
+  PatchArgs a;
+  a.x1 = x1; a.x2 = x2; a.w = w; a.bias = bias; a.res = res; a.y = y;
+  a.C1 = d->C1; a.C2 = d->C2; a.Cin = Cin; a.Cout = d->Cout;
+  a.B = d->B; a.H = H; a.W = W; a.Hs = d->Hs; a.Ws = d->Ws; a.ups = d->ups; a.transposed = d->transposed;
+  a.TR = TR; a.PW = W + 2;
+  a.M = (int)M;
+  const long npix_src = (long)d->B * d->Hs * d->Ws;
+  a.x1_bytes = (unsigned)(npix_src * d->C1 * 2);
+  a.x2_bytes = (unsigned)(npix_src * d->C2 * 2);
+  a.w_bytes = (unsigned)((long)d->Cout * 9 * Cin * 2);
+  a.n_mtiles = dm_cdiv((long)d->B * H, TR);
+  const int mt_pad = (a.n_mtiles + 7) / 8 * 8;
+  if (bn64) {
+    a.n_ntiles = dm_cdiv(d->Cout, 64);
+    hipLaunchKernelGGL((conv_patch_kernel<64, 7>), dim3(mt_pad * a.n_ntiles), dim3(NTHREADS), 0, st, a);
+  } else {
+    a.n_ntiles = dm_cdiv(d->Cout, 128);
+    hipLaunchKernelGGL((conv_patch_kernel<128, 6>), dim3(mt_pad * a.n_ntiles), dim3(NTHREADS), 0, st, a);
+  }
+  return DM_OK;
+}

@@ -13,3 +13,12 @@ void dm_set_error(const char* fmt, ...) {
 
 extern "C" const char* dm_last_error(void) { return g_err; }
 extern "C" int dm_abi_version(void) { return 1; }
+
+// run-time switches (tests exercise both convolution paths)
+int g_dm_use_patch_kernel = 1;
+
+extern "C" int dm_config_set(const char* key, int value) {
+  if (key && !strcmp(key, "conv_patch")) { g_dm_use_patch_kernel = value; return DM_OK; }
+  dm_set_error("dm_config_set: unknown key '%s'", key ? key : "(null)");
+  return DM_ERR_ARG;
+}

@@ -38,6 +38,7 @@ class LinearItem(ctypes.Structure):
 P = c_void_p
 _SIGNATURES = {
     "dm_abi_version": (c_int, []),
+    "dm_config_set": (c_int, [ctypes.c_char_p, c_int]),
     "dm_conv2d_igemm": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "dm_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "dm_pack_conv_weight": (c_int, [P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, P, P]),

@@ -30,6 +30,8 @@ typedef enum dm_status {
 
 const char* dm_last_error(void);
 int dm_abi_version(void);
+/* run-time switches: "conv_patch" (default 1): 3x3 stride-1 convs use the LDS-staged-patch kernel */
+int dm_config_set(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on bf16 MFMA.

@@ -47,8 +47,28 @@ CONV_CASES = [
 ]
 
 
+CONV_CASES += [
+    (2, 64, 0, 128, 32, 32, 3, 1, 0),       # tiles of 8 whole rows inside one image
+    (3, 128, 0, 128, 16, 16, 3, 1, 0),      # one image per tile
+    (9, 64, 64, 64, 8, 8, 3, 1, 0),         # four whole images per tile, ragged last tile, two sources
+    (3, 64, 0, 64, 28, 28, 3, 1, 0),        # tiles straddle image boundaries at arbitrary rows
+    (11, 128, 0, 64, 7, 7, 3, 1, 0),
+    (2, 64, 0, 64, 8, 8, 3, 1, 1),          # fused upsample through the patch path
+]
+
+
+@pytest.mark.parametrize("patch", [1, 0])
 @pytest.mark.parametrize("B,C1,C2,Cout,H,W,k,stride,ups", CONV_CASES)
-def test_conv2d_fwd_bwd(B, C1, C2, Cout, H, W, k, stride, ups):
+def test_conv2d_fwd_bwd(B, C1, C2, Cout, H, W, k, stride, ups, patch):
+    from dm_hip import ops, lib
+    lib.dm_config_set(b"conv_patch", patch)
+    try:
+        _conv2d_case(B, C1, C2, Cout, H, W, k, stride, ups)
+    finally:
+        lib.dm_config_set(b"conv_patch", 1)
+
+
+def _conv2d_case(B, C1, C2, Cout, H, W, k, stride, ups):
     from dm_hip import ops
     rs = np.random.RandomState(hash((B, C1, C2, Cout, H, W, k, stride, ups)) % (2 ** 31))
     pad = (k - 1) // 2

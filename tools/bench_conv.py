@@ -67,13 +67,16 @@ def main():
         d = ConvDesc(B, H, W, C1, C2, Cout, k, k, stride, pad, ups, 0, Ho, Wo)
         dt = ConvDesc(B, Ho, Wo, Cout, 0, Cin, k, k, stride, pad, 0, 1, Hi, Wi)
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        lib.dm_config_set(b"conv_patch", 0)
+        t_f0 = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(d), p(x1), p(x2), p(w), None, None, p(y), st)))
+        lib.dm_config_set(b"conv_patch", 1)
         t_f = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(d), p(x1), p(x2), p(w), None, None, p(y), st)))
         t_d = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(dt), p(dy), None, p(wt), None, None, p(dx), st)))
         t_w = timeit(lambda: check(lib.dm_conv2d_wgrad(ctypes.byref(d), p(x1), p(x2), p(dy), p(dw), st)))
         for key, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
             tot[key][0] += flops
             tot[key][1] += t
-        print(f"{name:24s} M={B*Ho*Wo:6d} N={Cout:4d} K={Cin*k*k:5d} GF={flops/1e9:7.1f} | fwd {t_f*1e3:7.1f}us {flops/t_f/1e9:7.0f} TF"
+        print(f"{name:24s} M={B*Ho*Wo:6d} N={Cout:4d} K={Cin*k*k:5d} GF={flops/1e9:7.1f} | gather-fwd {flops/t_f0/1e9:5.0f} TF | fwd {t_f*1e3:7.1f}us {flops/t_f/1e9:7.0f} TF"
               f" | dgrad {t_d*1e3:7.1f}us {flops/t_d/1e9:7.0f} TF | wgrad {t_w*1e3:7.1f}us {flops/t_w/1e9:7.0f} TF", flush=True)
     for key, (f, t) in tot.items():
         if t:
