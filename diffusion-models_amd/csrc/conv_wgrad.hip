@@ -17,7 +17,6 @@
 namespace {
 
 constexpr int BKM = 64;  // pixels per step
-constexpr int NTHREADS = 256;
 
 struct WgradArgs {
   const void* x1;
@@ -26,13 +25,19 @@ struct WgradArgs {
   float* dw;
   int C1, C2, Cin, Cout;
   int B, Hs, Ws, Hi, Wi, Ho, Wo, KH, KW, stride, pad, ups;
-  int M, splitk, rows_per_split, n_co_tiles, n_ci_tiles, xcd_major;
+  int M, splitk, rows_per_split, n_co_tiles, n_ci_tiles, n_blocks;
   unsigned x1_bytes, x2_bytes, dy_bytes;
   unsigned magic_hw, shift_hw, magic_w, shift_w;
+  int db_step, dh_step, dw_step;  // 64 pixels as (images, rows, columns) of the output
 };
 
 __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned magic, unsigned shift) {
   return (__umulhi(n, magic) + n) >> shift;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // swizzle of the 16-byte piece index within a row, by row; PPR = pieces per row (16: 256-byte rows, 8: 128-byte)
@@ -42,52 +47,87 @@ __device__ __forceinline__ int swz(int row) {
   return ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1);
 }
 
-template <int TW>  // tile width in channels (64 or 128)
+template <int TW, int NT>  // tile width in channels (64 or 128), threads per workgroup
 struct Tile {
   static constexpr int PPR = TW / 8;
   static constexpr int ROW_BYTES = TW * 2;
   static constexpr int BYTES = BKM * ROW_BYTES;
-  static constexpr int PIECES = BKM * PPR / NTHREADS;  // per thread
-  static constexpr int ROW_STEP = NTHREADS / PPR;
+  static constexpr int PIECES = BKM * PPR / NT;  // per thread
+  static constexpr int ROW_STEP = NT / PPR;
 };
 
+// Per-lane byte offset (within a tile) of the first transposing read of the fragment whose 16 channels start at
+// colbase; the second read of the fragment is 4 rows further, the fragment of the next 32 pixels 32 rows further
+// (both keep the swizzle term, which only looks at row bits 0, 1 and 3).
 template <int TW>
-__device__ __forceinline__ bf16x8_t read_frag(const char* tile, int colbase, int kk, int lane) {
-  using T = Tile<TW>;
+__device__ __forceinline__ int frag_offset(int colbase, int lane) {
+  constexpr int PPR = TW / 8, ROW_BYTES = TW * 2;
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
   const int piece = (colbase >> 3) + (p >> 1);
-  const int inner = (p & 1) * 8;
-  const int r0 = kk * 32 + 8 * g + q;
-  const int r1 = r0 + 4;
-  const char* p0 = tile + r0 * T::ROW_BYTES + ((piece ^ swz<T::PPR>(r0)) << 4) + inner;
-  const char* p1 = tile + r1 * T::ROW_BYTES + ((piece ^ swz<T::PPR>(r1)) << 4) + inner;
-  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
-  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+  const int r0 = 8 * g + q;
+  return r0 * ROW_BYTES + ((piece ^ swz<PPR>(r0)) << 4) + (p & 1) * 8;
+}
+
+// Two ds_read_b64_tr_b16 give a lane its 8 consecutive pixels of one channel. Issued as inline asm so that the
+// compiler does not drain the LDS-DMA ring (vmcnt(0)) in front of them; the caller waits with frag_wait().
+template <int OFF0, int OFF1>
+__device__ __forceinline__ void read_frag(s16x4_t& lo, s16x4_t& hi, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=&v"(lo), "=&v"(hi)
+               : "v"(addr), "i"(OFF0), "i"(OFF1));
+}
+
+__device__ __forceinline__ bf16x8_t join_frag(s16x4_t lo, s16x4_t hi) {
   s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int TCO, int TCI>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(WgradArgs a) {
-  using TY = Tile<TCO>;
-  using TX = Tile<TCI>;
+// Wait for every outstanding LDS read; naming the destinations read-write keeps their consumers below the wait.
+__device__ __forceinline__ void frag_wait(s16x4_t (&a)[4], s16x4_t (&b)[4], s16x4_t (&c)[4], s16x4_t (&d)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                 "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+}
+__device__ __forceinline__ void frag_wait(s16x4_t (&a)[4], s16x4_t (&b)[4], s16x4_t (&c)[2], s16x4_t (&d)[2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                 "+v"(c[0]), "+v"(c[1]), "+v"(d[0]), "+v"(d[1]));
+}
+__device__ __forceinline__ void frag_wait(s16x4_t (&a)[2], s16x4_t (&b)[2], s16x4_t (&c)[4], s16x4_t (&d)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]),
+                 "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+}
+__device__ __forceinline__ void frag_wait(s16x4_t (&a)[2], s16x4_t (&b)[2], s16x4_t (&c)[2], s16x4_t (&d)[2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1]), "+v"(d[0]), "+v"(d[1]));
+}
+
+// One workgroup per CU: KG groups of 4 waves; group g multiplies pixels [32g, 32g+32) of every 64-pixel step (KG = 2)
+// or all 64 (KG = 1), so each SIMD holds KG waves that hide each other's LDS latency. The tiles move through a ring
+// of NST LDS stages filled by buffer_load ... lds NST-1 steps ahead; a step waits only for its own stage (counted
+// vmcnt; steps beyond the end still issue their loads, out of range = zero fill, to keep the count fixed).
+template <int TCO, int TCI, int NST, int KG>
+__global__ __launch_bounds__(256 * KG, 1) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int NT = 256 * KG;
+  using TY = Tile<TCO, NT>;
+  using TX = Tile<TCI, NT>;
   constexpr int STAGE = TY::BYTES + TX::BYTES;
+  constexpr int LPS = TY::PIECES + TX::PIECES;  // loads per thread per stage
   constexpr int EP_PITCH = TCI + 4;
   constexpr int EP_BYTES = TCO * EP_PITCH * 4;
-  constexpr int TOTAL = (2 * STAGE > EP_BYTES) ? 2 * STAGE : EP_BYTES;
-  constexpr int MI = TCO / 32, NJ = TCI / 32;  // 16x16 tiles per wave (waves 2x2)
+  constexpr int TOTAL = (NST * STAGE > EP_BYTES) ? NST * STAGE : EP_BYTES;
+  constexpr int MI = TCO / 32, NJ = TCI / 32;  // 16x16 tiles per wave (waves 2x2 per group)
+  static_assert(LPS * (NST - 2) < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(16))) char smem[TOTAL];
 
-  int ks, inner;
+  // XCD x runs the contiguous range [x*n/8, (x+1)*n/8) of logical ids, ordered pixel-slice major, so the taps and
+  // tiles of one pixel slice (which re-read the same rows) sit on one XCD's L2
   const int per = a.KH * a.KW * a.n_co_tiles * a.n_ci_tiles;
-  if (a.xcd_major) {
-    // slices of the pixel axis are dealt to XCDs: all taps/tiles of one slice re-read the same rows from one L2
-    dm_xcd_tile(blockIdx.x, per, ks, inner);
-    if (ks >= a.splitk) return;
-  } else {
-    ks = blockIdx.x / per;
-    inner = blockIdx.x - ks * per;
-  }
+  const int logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (logical >= a.n_blocks) return;
+  const int ks = logical / per;
+  const int inner = logical - ks * per;
   const int tiles = a.n_co_tiles * a.n_ci_tiles;
   const int tap = inner / tiles;
   const int rest = inner - tap * tiles;
@@ -99,7 +139,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(WgradArgs a) {
   const int cioff = second ? ci0 - a.C1 : ci0;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
 
   __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(second ? a.x2 : a.x1), 0,
                                                                  second ? a.x2_bytes : a.x1_bytes, 0x00020000);
@@ -118,34 +158,68 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(WgradArgs a) {
   const bool ycol_ok = co0 + ypiece * 8 < a.Cout;
   const bool xcol_ok = cioff + xpiece * 8 < csrc;
 
-  auto stage = [&](int step, int buf) {
-    char* sy = smem + buf * STAGE;
+  // Row cursors. A thread stages the same row slots in every step and consecutive steps are 64 pixels apart, so
+  // the (image, row, column) of a slot is decoded once with divisions and then advanced by a fixed (db, dh, dw)
+  // with one carry each; addresses need only full-rate 24-bit multiply-adds (pixel counts and row pitches are far
+  // below 2^24 and the byte offsets below 2^31).
+  int cb[TX::PIECES], coh[TX::PIECES], cow[TX::PIECES];  // image * Hs, output row, output column
+  const int sshift = a.stride - 1, hs_step = a.db_step * a.Hs;
+#pragma unroll
+  for (int i = 0; i < TX::PIECES; ++i) {
+    const unsigned m = (unsigned)(m_begin + xrow + TX::ROW_STEP * i);
+    const unsigned b = fastdiv(m, a.magic_hw, a.shift_hw);
+    const unsigned r = m - b * (unsigned)(a.Ho * a.Wo);
+    const unsigned oh = fastdiv(r, a.magic_w, a.shift_w);
+    cb[i] = (int)b * a.Hs; coh[i] = (int)oh; cow[i] = (int)(r - oh * (unsigned)a.Wo);
+  }
+  unsigned yoff[TY::PIECES];
+#pragma unroll
+  for (int i = 0; i < TY::PIECES; ++i)
+    yoff[i] = (unsigned)(((m_begin + yrow + TY::ROW_STEP * i) * a.Cout + co0 + ypiece * 8) * 2);
+  const unsigned ystep = (unsigned)(BKM * a.Cout * 2);
+  const int xconst = (cioff + xpiece * 8) * 2, csrc2 = csrc * 2;
+  int mb = m_begin;  // first pixel of the next step to stage
+
+  auto stage = [&](int step) {  // called with step = 0, 1, 2, ... in order
+    char* sy = smem + (step % NST) * STAGE;
     char* sx = sy + TY::BYTES;
-    const int mb = m_begin + step * BKM;
 #pragma unroll
     for (int i = 0; i < TY::PIECES; ++i) {
-      int m = mb + yrow + TY::ROW_STEP * i;
-      unsigned off = (m < m_end && ycol_ok) ? (unsigned)((m * a.Cout + co0 + ypiece * 8) * 2) : DM_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, DM_LDS(sy + (wave * 64 + NTHREADS * i) * 16), 16, off, 0, 0, 0);
+      const int m = mb + yrow + TY::ROW_STEP * i;
+      const unsigned off = (m < m_end && ycol_ok) ? yoff[i] : DM_OOB;
+      yoff[i] += ystep;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, DM_LDS(sy + (wave * 64 + NT * i) * 16), 16, off, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < TX::PIECES; ++i) {
-      int m = mb + xrow + TX::ROW_STEP * i;
-      unsigned off = DM_OOB;
-      if (m < m_end && xcol_ok) {
-        unsigned b = fastdiv((unsigned)m, a.magic_hw, a.shift_hw);
-        unsigned r = (unsigned)m - b * (unsigned)(a.Ho * a.Wo);
-        unsigned oh = fastdiv(r, a.magic_w, a.shift_w);
-        unsigned ow = r - oh * (unsigned)a.Wo;
-        int ih = (int)oh * a.stride - a.pad + kh, iw = (int)ow * a.stride - a.pad + kw;
-        if (ih >= 0 && iw >= 0 && ih < a.Hi && iw < a.Wi) {
-          ih >>= a.ups; iw >>= a.ups;
-          off = (unsigned)(((((int)b * a.Hs + ih) * a.Ws + iw) * csrc + cioff + xpiece * 8) * 2);
-        }
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, DM_LDS(sx + (wave * 64 + NTHREADS * i) * 16), 16, off, 0, 0, 0);
+      const int m = mb + xrow + TX::ROW_STEP * i;
+      int ih = (coh[i] << sshift) - a.pad + kh, iw = (cow[i] << sshift) - a.pad + kw;   // stride is 1 or 2
+      const bool ok = m < m_end && xcol_ok && ih >= 0 && iw >= 0 && ih < a.Hi && iw < a.Wi;
+      ih >>= a.ups; iw >>= a.ups;
+      const unsigned pix = (unsigned)__umul24((unsigned)(cb[i] + ih), (unsigned)a.Ws) + iw;
+      const unsigned off = ok ? (unsigned)__umul24(pix, (unsigned)csrc2) + xconst : DM_OOB;
+      // advance the cursor by one step
+      cow[i] += a.dw_step;
+      const int c1 = cow[i] >= a.Wo;
+      cow[i] -= c1 ? a.Wo : 0;
+      coh[i] += a.dh_step + c1;
+      const int c2 = coh[i] >= a.Ho;
+      coh[i] -= c2 ? a.Ho : 0;
+      cb[i] += hs_step + (c2 ? a.Hs : 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, DM_LDS(sx + (wave * 64 + NT * i) * 16), 16, off, 0, 0, 0);
     }
+    mb += BKM;
   };
+
+  // fragment read addresses within a stage
+  const unsigned lds_base = (unsigned)(size_t)DM_LDS(smem);
+  unsigned a_off[MI], b_off[NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+    a_off[i] = frag_offset<TCO>(wm * (TCO / 2) + i * 16, lane) + (KG == 2 ? kg * 32 * TY::ROW_BYTES : 0);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    b_off[j] = TY::BYTES + frag_offset<TCI>(wn * (TCI / 2) + j * 16, lane) + (KG == 2 ? kg * 32 * TX::ROW_BYTES : 0);
 
   f32x4_t acc[MI][NJ];
 #pragma unroll
@@ -153,42 +227,70 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  if (nsteps > 0) stage(0, 0);
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) stage(s);
   for (int s = 0; s < nsteps; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (s + 1 < nsteps) stage(s + 1, (s + 1) & 1);
-    const char* sy = smem + (s & 1) * STAGE;
-    const char* sx = sy + TY::BYTES;
+    // this step's stage has landed for this wave (NST-2 younger stages may still be in flight) ...
+    wait_vmcnt<LPS*(NST - 2)>();
+    // ... and for every wave; every wave is also done reading the stage of step s-1, which is refilled next
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned sbase = lds_base + (unsigned)((s % NST) * STAGE);
+    auto compute = [&]() {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t af[MI], bfr[NJ];
+      for (int kq = 0; kq < 2 / KG; ++kq) {
+        // KG == 2: the wave group's half of the step is folded into a_off/b_off; KG == 1: both halves by immediate
+        s16x4_t alo[MI], ahi[MI], blo[NJ], bhi[NJ];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = read_frag<TCO>(sy, wm * (TCO / 2) + i * 16, kk, lane);
+        for (int i = 0; i < MI; ++i) {
+          if (kq == 0) read_frag<0, 4 * TY::ROW_BYTES>(alo[i], ahi[i], sbase + a_off[i]);
+          else read_frag<32 * TY::ROW_BYTES, 36 * TY::ROW_BYTES>(alo[i], ahi[i], sbase + a_off[i]);
+        }
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bfr[j] = read_frag<TCI>(sx, wn * (TCI / 2) + j * 16, kk, lane);
+        for (int j = 0; j < NJ; ++j) {
+          if (kq == 0) read_frag<0, 4 * TX::ROW_BYTES>(blo[j], bhi[j], sbase + b_off[j]);
+          else read_frag<32 * TX::ROW_BYTES, 36 * TX::ROW_BYTES>(blo[j], bhi[j], sbase + b_off[j]);
+        }
+        frag_wait(alo, ahi, blo, bhi);
+        bf16x8_t af[MI], bfr[NJ];
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) af[i] = join_frag(alo[i], ahi[i]);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
+        for (int j = 0; j < NJ; ++j) bfr[j] = join_frag(blo[j], bhi[j]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    };
+    stage(s + NST - 1);
+    compute();
   }
 
-  // ---- epilogue: transpose through LDS, then row-contiguous fp32 atomics
+  // ---- epilogue: sum the wave groups and transpose through LDS, then row-contiguous fp32 atomics
+  wait_vmcnt<0>();  // the trailing zero-fill loads must have landed before LDS is reused
   __syncthreads();
   float* ep = (float*)smem;
   const int frow = lane & 15, fq = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int g = 0; g < KG; ++g) {
+    if (kg == g) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        ep[(wm * (TCO / 2) + i * 16 + fq * 4 + r) * EP_PITCH + wn * (TCI / 2) + j * 16 + frow] = acc[i][j][r];
-  __syncthreads();
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* e = ep + (wm * (TCO / 2) + i * 16 + fq * 4 + r) * EP_PITCH + wn * (TCI / 2) + j * 16 + frow;
+            *e = (g == 0) ? acc[i][j][r] : *e + acc[i][j][r];
+          }
+    }
+    __syncthreads();
+  }
   const int T = a.KH * a.KW;
-  for (int item = tid; item < TCO * TCI; item += NTHREADS) {
+  for (int item = tid; item < TCO * TCI; item += NT) {
     int row = item / TCI, col = item - row * TCI;
     int co = co0 + row, ci = ci0 + col;
     if (co < a.Cout)
@@ -235,6 +337,9 @@ extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void
   a.dy_bytes = (unsigned)(M * d->Cout * 2);
   make_magic((unsigned)(d->Ho * d->Wo), a.magic_hw, a.shift_hw);
   make_magic((unsigned)d->Wo, a.magic_w, a.shift_w);
+  a.db_step = BKM / (d->Ho * d->Wo);
+  a.dh_step = (BKM % (d->Ho * d->Wo)) / d->Wo;
+  a.dw_step = (BKM % (d->Ho * d->Wo)) % d->Wo;
 
   const bool wide_co = d->Cout % 128 == 0;
   const bool wide_ci = d->C1 % 128 == 0 && d->C2 % 128 == 0;
@@ -242,22 +347,33 @@ extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void
   a.n_co_tiles = dm_cdiv(d->Cout, tco);
   a.n_ci_tiles = a.Cin / tci;
   const int per = d->KH * d->KW * a.n_co_tiles * a.n_ci_tiles;
-  // split the pixel axis so the launch has >= ~2 workgroups per CU, but keep >= 8 steps per workgroup
+  // One workgroup per CU: split the pixel axis so that one round of workgroups covers the chip (every further
+  // split adds a full partial tile of fp32 atomics per workgroup), but keep >= 8 steps per workgroup.
   const int steps_total = dm_cdiv(M, BKM);
-  int splitk = dm_cdiv(768, per);
-  const int max_split = steps_total / 8 > 0 ? steps_total / 8 : 1;
-  if (splitk > max_split) splitk = max_split;
-  if (splitk < 1) splitk = 1;
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  // Split the pixel axis to minimise rounds x (steps per workgroup + fixed cost): one workgroup per CU per round,
+  // the fixed cost (pipeline fill, partial-tile atomics) counted as OVERHEAD steps.
+  constexpr int OVERHEAD = 7;
+  const int max_split = steps_total / 8 > 0 ? (steps_total / 8 < 64 ? steps_total / 8 : 64) : 1;
+  int splitk = 1;
+  long best = -1;
+  for (int sk = 1; sk <= max_split; ++sk) {
+    const long cost = (long)dm_cdiv(per * sk, n_cu) * (dm_cdiv(steps_total, sk) + OVERHEAD);
+    if (best < 0 || cost < best) { best = cost; splitk = sk; }
+  }
   a.rows_per_split = dm_cdiv(steps_total, splitk) * BKM;
   a.splitk = dm_cdiv(M, a.rows_per_split);
-  a.xcd_major = a.splitk >= 8;
-  const int ks_pad = a.xcd_major ? (a.splitk + 7) / 8 * 8 : a.splitk;
-  dim3 grid(ks_pad * per), block(NTHREADS);
+  a.n_blocks = a.splitk * per;
+  dim3 grid((a.n_blocks + 7) / 8 * 8), block(512);
   hipStream_t st = (hipStream_t)stream;
-  if (wide_co && wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, st, a);
-  else if (wide_co) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, st, a);
-  else if (wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, st, a);
+  if (wide_co && wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2>), grid, block, 0, st, a);
+  else if (wide_co) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 4, 2>), grid, block, 0, st, a);
+  else if (wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, 2>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 4, 2>), grid, block, 0, st, a);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

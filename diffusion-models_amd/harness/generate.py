@@ -1,0 +1,141 @@
+"""Batched, rank-sharded sample generation (reference: train.py:141-160 seeds, train.py:476-504 and
+save_fid_eval.py:126-172 generation loops).
+
+Each rank takes one contiguous shard of the (z, cls) seeds, runs the whole n-step sampler on batches of
+`batch_size` independently (no collective inside the loop), clips to [-1, 1] as the reference does, and the
+shards are gathered once at the end.
+
+The UNet forward of a sampler step is ~150 kernel launches whose arguments do not change from step to step
+except for the contents of z and t, so it is captured ONCE per (batch size, guidance mode) into a HIP graph
+that reads the sampler's own state buffer in place; a step is then one 8-byte-per-row copy of t, one graph
+launch and one fused update kernel.
+"""
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def make_generation_seed(dataset: str, n_examples: int, seed: Optional[int] = None, sample_labels: bool = False):
+    """train.py:141-160: z ~ N(0, I) and labels from (separate, identically seeded) CPU generators."""
+    def get_generator():
+        return torch.Generator().manual_seed(seed) if seed is not None else None
+
+    if dataset == "mnist":
+        image_shape, n_classes = (1, 28, 28), 10
+    elif dataset == "cifar10":
+        image_shape, n_classes = (3, 32, 32), 10
+    else:
+        raise ValueError(f"unknown dataset {dataset}")
+    z = torch.randn((n_examples, *image_shape), generator=get_generator())
+    if sample_labels:
+        cls = torch.randint(0, n_classes, (n_examples,), generator=get_generator())
+    else:
+        cls = torch.arange(n_examples) % n_classes
+    return {"z": z, "cls": cls}
+
+
+class GraphedPredictor:
+    """pred_fn(z, t) replayed from a HIP graph.
+
+    The graph is captured at the first call, against the z buffer of that call (samplers update their state in
+    place, so every later step passes the same buffer and no copy of z is needed; a different buffer of the
+    same shape is copied into the captured one). t is copied into a captured int64 buffer. The returned
+    prediction is the graph's output buffer: it is overwritten by the next call, which is what a sampler loop
+    wants (the update kernel consumes it before the next forward).
+    """
+
+    def __init__(self, pred_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], warmup: int = 2):
+        self.pred_fn = pred_fn
+        self.warmup = warmup
+        self.graph = None
+        self.z = self.t = self.out = None
+
+    def _capture(self, z, t):
+        self.z = z
+        self.t = t.clone()
+        side = torch.cuda.Stream(device=z.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(self.warmup):  # packs weights, sizes workspaces
+                self.pred_fn(self.z, self.t)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = self.pred_fn(self.z, self.t)
+
+    def __call__(self, z, t):
+        if self.graph is None or z.shape != self.z.shape or z.dtype != self.z.dtype:
+            self._capture(z, t)
+        if z.data_ptr() != self.z.data_ptr():
+            self.z.copy_(z)
+        self.t.copy_(t)
+        self.graph.replay()
+        return self.out
+
+
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of n items for `rank`; the first n % world ranks hold one more item."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+@torch.no_grad()
+def generate(model, sampler, scheduler, z: torch.Tensor, cls: Optional[torch.Tensor] = None,
+             guidance_scale: float = 1.0, batch_size: int = 256, use_graph: bool = True,
+             process_group=None, gather: bool = True, sampler_kwargs: Optional[Dict] = None) -> torch.Tensor:
+    """Generate one image per row of z (train.py:476-504), sharded over the ranks of `process_group`.
+
+    z / cls are the full seed tensors (host or device), identical on every rank. Returns the clipped fp32
+    samples on the host: all of them on every rank when `gather`, else this rank's shard.
+    Every batch starts its own `sampler.sample()` call, so a DDPM sampler re-creates its default-seeded noise
+    generator per batch exactly as the reference does.
+    """
+    device = next(model.parameters()).device
+    world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(process_group) if world > 1 else 0
+    lo, hi = shard_bounds(z.size(0), world, rank)
+    was_training = model.training
+    model.eval()
+    sampler_kwargs = sampler_kwargs or {}
+    graphed: Dict[Tuple, GraphedPredictor] = {}
+    cond_buf: Dict[int, torch.Tensor] = {}
+    outs = []
+    for b0 in range(lo, hi, batch_size):
+        b1 = min(hi, b0 + batch_size)
+        zb = z[b0:b1].to(device)
+        cond = None
+        if cls is not None:
+            # one persistent label buffer per batch size: a captured graph keeps reading it
+            cond = cond_buf.setdefault(b1 - b0, torch.empty(b1 - b0, dtype=torch.int64, device=device))
+            cond.copy_(cls[b0:b1])
+        if use_graph:
+            key = (b1 - b0, cond is not None)
+            if key not in graphed:
+                graphed[key] = GraphedPredictor(model.get_pred_fn(cond=cond, guidance_scale=guidance_scale))
+            pred_fn = graphed[key]
+        else:
+            pred_fn = model.get_pred_fn(cond=cond, guidance_scale=guidance_scale)
+        samples = sampler.sample(zb, scheduler, pred_fn, **sampler_kwargs)
+        outs.append(torch.clip(samples, -1, 1).cpu())
+    if was_training:
+        model.train()
+    shape = tuple(z.shape[1:])
+    mine = torch.cat(outs, dim=0) if outs else torch.empty((0, *shape), dtype=torch.float32)
+    if world == 1 or not gather:
+        return mine
+    return gather_shards(mine, z.size(0), world, process_group, device)
+
+
+def gather_shards(mine: torch.Tensor, n_total: int, world: int, process_group=None, device=None) -> torch.Tensor:
+    """The one collective of generation: all_gather of the per-rank shards (padded to the largest shard)."""
+    backend = dist.get_backend(process_group)
+    dev = device if backend == "nccl" else torch.device("cpu")
+    longest = max(shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world))
+    padded = torch.zeros((longest, *mine.shape[1:]), dtype=mine.dtype, device=dev)
+    padded[:mine.size(0)] = mine.to(dev)
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=process_group)
+    sizes = [shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world)]
+    return torch.cat([p[:s].cpu() for p, s in zip(parts, sizes)], dim=0)

@@ -46,6 +46,7 @@ def main():
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     only = sys.argv[1] if len(sys.argv) > 1 else None
+    which = sys.argv[2] if len(sys.argv) > 2 else "fdw"   # f(orward) d(ata gradient) w(eight gradient)
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
     for name, B, H, W, C1, C2, Cout, k, stride, ups in SHAPES:
         if only and only not in name:
@@ -67,12 +68,16 @@ def main():
         d = ConvDesc(B, H, W, C1, C2, Cout, k, k, stride, pad, ups, 0, Ho, Wo)
         dt = ConvDesc(B, Ho, Wo, Cout, 0, Cin, k, k, stride, pad, 0, 1, Hi, Wi)
         p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-        lib.dm_config_set(b"conv_patch", 0)
-        t_f0 = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(d), p(x1), p(x2), p(w), None, None, p(y), st)))
-        lib.dm_config_set(b"conv_patch", 1)
-        t_f = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(d), p(x1), p(x2), p(w), None, None, p(y), st)))
-        t_d = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(dt), p(dy), None, p(wt), None, None, p(dx), st)))
-        t_w = timeit(lambda: check(lib.dm_conv2d_wgrad(ctypes.byref(d), p(x1), p(x2), p(dy), p(dw), st)))
+        t_f0 = t_f = t_d = t_w = float("inf")
+        if "f" in which:
+            lib.dm_config_set(b"conv_patch", 0)
+            t_f0 = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(d), p(x1), p(x2), p(w), None, None, p(y), st)))
+            lib.dm_config_set(b"conv_patch", 1)
+            t_f = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(d), p(x1), p(x2), p(w), None, None, p(y), st)))
+        if "d" in which:
+            t_d = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(dt), p(dy), None, p(wt), None, None, p(dx), st)))
+        if "w" in which:
+            t_w = timeit(lambda: check(lib.dm_conv2d_wgrad(ctypes.byref(d), p(x1), p(x2), p(dy), p(dw), st)))
         for key, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
             tot[key][0] += flops
             tot[key][1] += t
