@@ -370,6 +370,50 @@ __global__ void colsum_f32_kernel(const float* __restrict__ x, float* __restrict
   out[c] += s;
 }
 
+// ---- batched [Cout][T][Cin] -> [Cin][T][Cout] transposition of bf16 weights living in one arena ------------
+// One workgroup moves one 64x64 (co, ci) tile of one tap through LDS; the item table is device memory so a
+// captured graph can replay the launch.
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const short* __restrict__ src, short* __restrict__ dst,
+                                                                const dm_wt_item* __restrict__ items, int n_items) {
+  __shared__ short tile[64][66];
+  const int bid = blockIdx.x;
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {  // last item whose tile_begin <= bid
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].tile_begin <= bid) lo = mid; else hi = mid - 1;
+  }
+  const dm_wt_item it = items[lo];
+  const int tci = (it.Cin + 63) >> 6, tco = (it.Cout + 63) >> 6;
+  int r = bid - it.tile_begin;
+  const int t = r / (tco * tci);
+  r -= t * tco * tci;
+  const int co0 = (r / tci) << 6, ci0 = (r % tci) << 6;
+  const short* s = src + it.offset;
+  short* d = dst + it.offset;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int piece = tid + 256 * k, row = piece >> 3, c8 = (piece & 7) << 3;
+    const int co = co0 + row, ci = ci0 + c8;
+    s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (co < it.Cout && ci < it.Cin) v = *(const s16x8_t*)(s + ((long)co * it.T + t) * it.Cin + ci);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[row][c8 + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int piece = tid + 256 * k, row = piece >> 3, c8 = (piece & 7) << 3;  // row: ci, c8: co
+    const int ci = ci0 + row, co = co0 + c8;
+    if (ci < it.Cin && co < it.Cout) {
+      s16x8_t v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[c8 + e][row];
+      *(s16x8_t*)(d + ((long)ci * it.T + t) * it.Cout + co) = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int dm_timestep_embed(const int64_t* t, const float* freq, float* out, int B, int half, void* stream) {
@@ -523,6 +567,16 @@ extern "C" int dm_pack_conv_weight(const float* w, long s_co, long s_ci, long s_
   const long total = (long)Cout * Cin * KH * KW;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(dm_cdiv(total, NT)), dim3(NT), 0, (hipStream_t)stream, w, s_co, s_ci, s_kh, s_kw,
                      Cout, Cin, KH, KW, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_transpose_conv_weights(const void* src, void* dst, const dm_wt_item* items_dev, int n_items,
+                                         int n_tiles, void* stream) {
+  DM_REQUIRE(src && dst && items_dev && n_items > 0 && n_tiles > 0, DM_ERR_ARG, "dm_transpose_conv_weights: bad argument");
+  DM_REQUIRE(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, DM_ERR_ARG, "dm_transpose_conv_weights: arenas must be 16-byte aligned");
+  hipLaunchKernelGGL(transpose_weights_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, (const short*)src,
+                     (short*)dst, items_dev, n_items);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

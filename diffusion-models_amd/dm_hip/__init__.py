@@ -35,6 +35,11 @@ class LinearItem(ctypes.Structure):
                 ("db", c_void_p), ("N", c_int)]
 
 
+class WtItem(ctypes.Structure):
+    """dm_wt_item: one weight of a batched forward->data-gradient re-layout (element offset, dims, first tile)."""
+    _fields_ = [("offset", c_long), ("Cout", c_int), ("T", c_int), ("Cin", c_int), ("tile_begin", c_int)]
+
+
 P = c_void_p
 _SIGNATURES = {
     "dm_abi_version": (c_int, []),
@@ -42,6 +47,7 @@ _SIGNATURES = {
     "dm_conv2d_igemm": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "dm_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "dm_pack_conv_weight": (c_int, [P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, P, P]),
+    "dm_transpose_conv_weights": (c_int, [P, P, P, c_int, c_int, P]),
     "dm_colsum_bf16": (c_int, [P, P, c_long, c_int, P]),
     "dm_colsum_f32": (c_int, [P, P, c_int, c_int, P]),
     "dm_in_conv_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -98,8 +98,19 @@ class WeightPack:
         self.key = None
         self.w_fwd = None
         self.w_dgrad = None
+        self.bound = None
+
+    def bind(self, weight, w_fwd, w_dgrad):
+        """Use externally maintained copies (e.g. slices of a bf16 mirror of a parameter arena that the optimizer
+        kernel refreshes) for as long as `weight` is not rewritten through torch."""
+        self.bound = (weight.data_ptr(), weight._version, w_fwd, w_dgrad)
 
     def get(self, weight):
+        if self.bound is not None:
+            ptr, version, w_fwd, w_dgrad = self.bound
+            if weight.data_ptr() == ptr and weight._version == version:
+                return w_fwd, w_dgrad
+            self.bound = None  # the parameter was rewritten behind the mirror: pack it here from now on
         w4 = weight if weight.dim() == 4 else weight[:, :, None, None]
         key = (weight.data_ptr(), weight._version, weight.device, WEIGHTS_EPOCH)
         if FORCE_REPACK or key != self.key or self.w_fwd is None:

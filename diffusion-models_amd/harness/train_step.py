@@ -19,7 +19,9 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-from dm_hip import check, lib, ops
+import numpy as np
+
+from dm_hip import WtItem, check, lib, ops
 from harness.ddp import BucketedAllReduce
 from modeling.layers import Conv2d
 
@@ -75,6 +77,7 @@ class TrainStep:
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
         self.steps = 0
+        self._init_weight_mirrors()
         self.reducer = BucketedAllReduce(self.arena.grad, self.arena.offsets, bucket_mb << 20, process_group)
         self.world = self.reducer.world
         self._in_backward = False
@@ -84,6 +87,61 @@ class TrainStep:
             # place report through ops.GRAD_READY (set around backward)
             for _, p in self.arena.params:
                 p.register_post_accumulate_grad_hook(self._on_grad_ready)
+
+    # ---- bf16 weight mirrors ------------------------------------------------------------------------------
+    def _init_weight_mirrors(self):
+        """bf16 copies of the whole parameter arena in the two layouts the conv kernels read. The arena stores a
+        conv weight as [Cout][KH][KW][Cin] and a linear weight as [out][in], which IS the forward operand layout,
+        so the forward mirror is written by the optimizer kernel itself; the data-gradient mirror ([Cin][T][Cout]
+        at the same offsets) is one batched transposition per step instead of two packing launches per layer."""
+        a = self.arena
+        dev = a.data.device
+        self.w16 = torch.empty(a.numel, dtype=torch.bfloat16, device=dev)
+        self.w16_t = torch.zeros(a.numel, dtype=torch.bfloat16, device=dev)
+        offset_of = {id(p): o for (_, p), o in zip(a.params, a.offsets)}
+        items, tiles, self._bound = [], 0, []
+        for mod in self.model.modules():
+            pack, w = getattr(mod, "_pack", None), getattr(mod, "weight", None)
+            if not isinstance(pack, ops.WeightPack) or w is None or id(w) not in offset_of:
+                continue
+            if w.dim() == 4:
+                co, ci, kh, kw = w.shape
+                if w.stride() != (kh * kw * ci, 1, kw * ci, ci):
+                    continue
+            elif w.dim() == 2:
+                (co, ci), kh, kw = w.shape, 1, 1
+            else:
+                continue
+            if co % 8 or ci % 8:
+                continue
+            o = offset_of[id(w)]
+            items.append((o, co, kh * kw, ci, tiles))
+            tiles += kh * kw * ((co + 63) // 64) * ((ci + 63) // 64)
+            self._bound.append((pack, w, o, w.numel()))
+        self._wt_tiles = tiles
+        self._wt_items = None
+        if items:
+            rec = np.zeros(len(items), dtype=np.dtype([("offset", np.int64), ("Cout", np.int32), ("T", np.int32),
+                                                       ("Cin", np.int32), ("tile_begin", np.int32)]))
+            assert rec.dtype.itemsize == ctypes.sizeof(WtItem)
+            for i, it in enumerate(items):
+                rec[i] = it
+            self._wt_items = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+            self._wt_n = len(items)
+        self.refresh_packed()
+
+    def _transpose_mirror(self):
+        if self._wt_items is not None:
+            check(lib.dm_transpose_conv_weights(self.w16.data_ptr(), self.w16_t.data_ptr(), self._wt_items.data_ptr(),
+                                                self._wt_n, self._wt_tiles, torch.cuda.current_stream().cuda_stream))
+
+    def refresh_packed(self):
+        """Rebuild both mirrors from the fp32 arena and (re)bind them to the layers. Call after writing parameters
+        through torch (load_state_dict, copy_); the optimizer step keeps them current by itself."""
+        self.w16.copy_(self.arena.data)
+        self._transpose_mirror()
+        for pack, w, o, n in self._bound:
+            pack.bind(w, self.w16[o:o + n], self.w16_t[o:o + n])
 
     def _on_grad_ready(self, p):
         if self._in_backward:
@@ -110,10 +168,11 @@ class TrainStep:
         check(lib.dm_optimizer_tick(self.step_dev.data_ptr(), self.hyper.data_ptr(), self.lr, self.betas[0],
                                     self.betas[1], ig, pw, mx, st))
         check(lib.dm_adamw_ema_step(a.data.data_ptr(), a.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                    self.ema.data_ptr() if self.ema is not None else None, None,
+                                    self.ema.data_ptr() if self.ema is not None else None, self.w16.data_ptr(),
                                     self.norm.data_ptr() if self.clip > 0 else None, self.clip, a.numel, self.lr,
                                     self.betas[0], self.betas[1], self.eps, self.wd, 1.0, 1.0, 0.0,
                                     self.hyper.data_ptr(), st))
+        self._transpose_mirror()
         a.grad.zero_()
         self.steps += 1
         ops.WEIGHTS_EPOCH += 1  # packed bf16 copies of the weights are stale now

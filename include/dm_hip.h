@@ -69,6 +69,19 @@ int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const
 int dm_pack_conv_weight(const float* w, long s_co, long s_ci, long s_kh, long s_kw, int Cout, int Cin, int KH,
                         int KW, void* w_fwd, void* w_dgrad, void* stream);
 
+/* Batched re-layout of bf16 conv/linear weights that live in one arena in the forward layout [Cout][T][Cin]
+ * (the physical layout of the fp32 parameter arena, so the optimizer's bf16 copy IS the forward operand) into the
+ * data-gradient layout [Cin][T][Cout] at the same element offsets of a second arena. `items_dev` is DEVICE memory
+ * (n_items entries sorted by tile_begin; an item owns T * ceil(Cout/64) * ceil(Cin/64) tiles starting at tile_begin;
+ * offsets are elements and multiples of 8, Cout and Cin multiples of 8), n_tiles the total. Replaces the per-layer
+ * weight casts autocast performs in front of every conv/linear (modeling/blocks.py:51,70, attention.py:70,83). */
+typedef struct dm_wt_item {
+  long offset;
+  int Cout, T, Cin, tile_begin;
+} dm_wt_item;
+int dm_transpose_conv_weights(const void* src, void* dst, const dm_wt_item* items_dev, int n_items, int n_tiles,
+                              void* stream);
+
 /* out[c] += sum_m x[m][c]  (bias gradients; x bf16 [M][C], out fp32) */
 int dm_colsum_bf16(const void* x, float* out, long M, int C, void* stream);
 /* out[c] += sum_r x[r][c]  (x fp32 [R][C]) */

@@ -350,3 +350,32 @@ def test_adamw_ema_step_matches_torch():
         assert max_abs(p, ref.detach()) < 2e-6
         assert max_abs(ema, ema_ref) < 2e-6
         assert torch.equal(wb.float().cpu(), p.cpu().to(torch.bfloat16).float())
+
+
+def test_transpose_conv_weights_batched():
+    """Forward-layout [Cout][T][Cin] bf16 arena -> data-gradient layout [Cin][T][Cout] at the same offsets; exact."""
+    import ctypes
+
+    from dm_hip import WtItem, check, lib
+    shapes = [(128, 9, 64), (64, 1, 192), (72, 9, 8), (8, 4, 136)]  # (Cout, T, Cin), ragged tiles included
+    offs, items, o, tiles = [], [], 0, 0
+    for co, t, ci in shapes:
+        offs.append(o)
+        items.append((o, co, t, ci, tiles))
+        tiles += t * ((co + 63) // 64) * ((ci + 63) // 64)
+        o += (co * t * ci + 63) // 64 * 64
+    src = torch.randn(o, device=dev()).to(torch.bfloat16)
+    dst = torch.zeros_like(src)
+    rec = np.zeros(len(items), dtype=np.dtype([("offset", np.int64), ("Cout", np.int32), ("T", np.int32),
+                                               ("Cin", np.int32), ("tile_begin", np.int32)]))
+    assert rec.dtype.itemsize == ctypes.sizeof(WtItem)
+    for i, it in enumerate(items):
+        rec[i] = it
+    table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev())
+    check(lib.dm_transpose_conv_weights(src.data_ptr(), dst.data_ptr(), table.data_ptr(), len(items), tiles,
+                                        torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for (co, t, ci), off in zip(shapes, offs):
+        n = co * t * ci
+        want = src[off:off + n].view(co, t, ci).permute(2, 1, 0).contiguous().view(-1)
+        assert torch.equal(dst[off:off + n], want), (co, t, ci)
