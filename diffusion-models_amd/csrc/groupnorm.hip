@@ -10,6 +10,8 @@
 //             2. group sums from the workspace, then dx streamed; the first pixel-chunk of each sample also emits
 //                the parameter-side gradients (dgamma/dbeta atomics, dscale_shift, dpre_add)
 // The second sweep of each pair re-reads a tensor that was just read, which the 256 MiB Infinity Cache serves.
+// The workspace must be zero on entry and is zero again on exit: the last workgroup of a sample to have read the
+// sums (arrival counter behind the sums) clears them, so one buffer serves every call with no memset launches.
 // The channel axis may be the concatenation of two tensors (x1 | x2).
 #include "dm_common.h"
 
@@ -37,6 +39,7 @@ struct GnArgs {
   float* dss;
   float* dpre;
   float* ws;
+  int* cnt;  // per-sample arrival counters behind the sums
   int B, HW, C1, C2, C, G, cg, act, pch;
   float eps;
 };
@@ -69,6 +72,19 @@ __device__ __forceinline__ void reduce_to_global(float* red, const Lanes& L, int
     float s = 0.f;
     for (int q = 0; q < L.PL; ++q) s += red[((q * L.VP + vv) * NV + k) * 8 + j];
     atomicAdd(out + (size_t)k * C + c, s);
+  }
+}
+
+
+// Called by every workgroup of sample b after it has read ws[b]: the last arriver clears the sums and the counter.
+__device__ __forceinline__ void release_workspace(float* ws_b, int n, int* counter) {
+  __shared__ int s_last;
+  __syncthreads();  // every thread of this workgroup is done reading
+  if (threadIdx.x == 0) s_last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (s_last) {
+    for (int i = threadIdx.x; i < n; i += NT) ws_b[i] = 0.f;
+    if (threadIdx.x == 0) *counter = 0;
   }
 }
 
@@ -150,7 +166,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(GnArgs a) {
     s_ka[c] = ka;
     s_kb[c] = ka * (pv - mu) + sc * be + sh;  // u = sc * (ga * (x + pre - mu) * r + be) + sh
   }
-  __syncthreads();
+  release_workspace(a.ws + (size_t)b * 2 * a.C, 2 * a.C, a.cnt + b);
   const Lanes L(a.C);
   if (!L.active) return;
   const int c = 8 * L.v;
@@ -278,6 +294,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(GnArgs a) {
       }
     }
   }
+  release_workspace(a.ws + (size_t)b * 3 * a.C, 3 * a.C, a.cnt + b);
   const Lanes L(a.C);
   if (!L.active) return;
   const int c = 8 * L.v;
@@ -345,7 +362,7 @@ void fill(GnArgs& a, const dm_gn_desc* d) {
 }  // namespace
 
 extern "C" long dm_groupnorm_ws_floats(const dm_gn_desc* d) {
-  return d ? 3L * d->B * (d->C1 + d->C2) : 0;
+  return d ? 3L * d->B * (d->C1 + d->C2) + d->B : 0;
 }
 
 extern "C" int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma,
@@ -362,11 +379,8 @@ extern "C" int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const v
   a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.pre = pre_add;
   a.y = (bf16_t*)y; a.mean = mean; a.rstd = rstd; a.ws = ws;
   fill(a, d);
+  a.cnt = (int*)(ws + 3L * a.B * a.C);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * a.B * a.C, st) != hipSuccess) {
-    dm_set_error("dm_groupnorm_act_fwd: workspace memset failed");
-    return DM_ERR_LAUNCH;
-  }
   dim3 grid(dm_cdiv(a.HW, a.pch), a.B);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(NT), 0, st, a);
   DM_CHECK_LAUNCH();
@@ -398,11 +412,8 @@ extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const v
   a.dx1 = (bf16_t*)dx1; a.dx2 = (bf16_t*)dx2; a.dgamma = dgamma; a.dbeta = dbeta;
   a.dss = dscale_shift; a.dpre = dpre_add; a.ws = ws;
   fill(a, d);
+  a.cnt = (int*)(ws + 3L * a.B * a.C);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, sizeof(float) * 3 * a.B * a.C, st) != hipSuccess) {
-    dm_set_error("dm_groupnorm_act_bwd: workspace memset failed");
-    return DM_ERR_LAUNCH;
-  }
   dim3 grid(dm_cdiv(a.HW, a.pch), a.B);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(NT), 0, st, a);
   DM_CHECK_LAUNCH();

@@ -25,6 +25,19 @@ WEIGHTS_EPOCH = 0
 # extra add pass. GRAD_READY(param), if set, is told when such a gradient has been enqueued.
 DIRECT_GRADS = False
 GRAD_READY = None
+# When True (and DIRECT_GRADS), weight/bias gradient kernels of the convolutions are enqueued on a second stream:
+# they depend only on tensors that exist when a layer's backward starts and nothing but the optimizer reads their
+# results, so they overlap the data-gradient / GroupNorm chain. Whoever sets it must make the consumer of the
+# gradients wait for side_stream(device).
+SIDE_WGRAD = False
+_SIDE = {}
+
+
+def side_stream(device):
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 def _stream():
@@ -87,6 +100,19 @@ def _grad_done(param):
 
 def f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+_GN_WS = {}
+
+
+def _gn_workspace(device, floats):
+    """The per-device GroupNorm workspace: zero-filled once; the kernels hand it back zero-filled, so every call on
+    the device's stream shares it."""
+    ws = _GN_WS.get(device)
+    if ws is None or ws.numel() < floats:
+        ws = torch.zeros(max(floats, 1 << 20), dtype=torch.float32, device=device)
+        _GN_WS[device] = ws
+    return ws
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -172,6 +198,19 @@ class _ConvFn(Function):
         dy = as_nhwc(dy)
         st = _stream()
         dx1 = dx2 = dw = db = None
+        wparam, bparam = ctx.params
+        wsink = _grad_sink(wparam, ohwi=True) if ctx.needs_input_grad[2] else None
+        want_db = has_bias and ctx.needs_input_grad[3]
+        bsink = _grad_sink(bparam) if want_db else None
+        on_side = SIDE_WGRAD and (wsink is not None or not ctx.needs_input_grad[2]) and (bsink is not None or not want_db)
+        st_w = st
+        if on_side:
+            side = side_stream(dy.device)
+            side.wait_stream(torch.cuda.current_stream())  # dy (and the saved inputs) are complete
+            st_w = side.cuda_stream
+            for t in (dy, x1, x2):
+                if t is not None:
+                    t.record_stream(side)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             _, w_dgrad = pack.get(weight)
             dxf = empty_nhwc(B, Cin, Hi, Wi, dy.device)
@@ -186,23 +225,20 @@ class _ConvFn(Function):
                 dx1 = dxf
             else:
                 dx1, dx2 = dxf[:, :C1], dxf[:, C1:]
-        wparam, bparam = ctx.params
         if ctx.needs_input_grad[2]:
-            sink = _grad_sink(wparam, ohwi=True)
-            dwf = sink if sink is not None else torch.zeros((Cout, KH, KW, Cin), dtype=torch.float32, device=dy.device)
+            dwf = wsink if wsink is not None else torch.zeros((Cout, KH, KW, Cin), dtype=torch.float32, device=dy.device)
             d = _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, 0, Ho, Wo)
-            check(lib.dm_conv2d_wgrad(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(), st))
-            if sink is not None:
+            check(lib.dm_conv2d_wgrad(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(), st_w))
+            if wsink is not None:
                 _grad_done(wparam)
             else:
                 dw = dwf.permute(0, 3, 1, 2)
                 if weight.dim() == 2:
                     dw = dw.reshape(Cout, Cin)
-        if has_bias and ctx.needs_input_grad[3]:
-            sink = _grad_sink(bparam)
-            dbf = sink if sink is not None else torch.zeros(Cout, dtype=torch.float32, device=dy.device)
-            check(lib.dm_colsum_bf16(dy.data_ptr(), dbf.data_ptr(), B * Ho * Wo, Cout, st))
-            if sink is not None:
+        if want_db:
+            dbf = bsink if bsink is not None else torch.zeros(Cout, dtype=torch.float32, device=dy.device)
+            check(lib.dm_colsum_bf16(dy.data_ptr(), dbf.data_ptr(), B * Ho * Wo, Cout, st_w))
+            if bsink is not None:
                 _grad_done(bparam)
             else:
                 db = dbf
@@ -235,7 +271,7 @@ class _GroupNormActFn(Function):
         mean = torch.empty((B, G), dtype=torch.float32, device=x1.device)
         rstd = torch.empty((B, G), dtype=torch.float32, device=x1.device)
         d = GnDesc(B, H * W, C1, C2, G, eps, int(act), int(ss32 is not None), int(pre32 is not None))
-        ws = torch.empty(3 * B * C, dtype=torch.float32, device=x1.device)
+        ws = _gn_workspace(x1.device, 3 * B * C + B)
         check(lib.dm_groupnorm_act_fwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
                                        _p(ss32), _p(pre32), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                        ws.data_ptr(), _stream()))
@@ -263,7 +299,7 @@ class _GroupNormActFn(Function):
         dss = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if ss32 is not None else None
         dpre = torch.empty((B, C), dtype=torch.float32, device=dev) if pre32 is not None else None
         st = _stream()
-        ws = torch.empty(3 * B * C, dtype=torch.float32, device=dev)
+        ws = _gn_workspace(dev, 3 * B * C + B)
         check(lib.dm_groupnorm_act_bwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
                                        _p(ss32), _p(pre32), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), None,
                                        dx1.data_ptr(), _p(dx2), dg.data_ptr(), db_.data_ptr(), _p(dss),

@@ -60,11 +60,12 @@ class FlatArena:
 class TrainStep:
     def __init__(self, model, scheduler, lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2,
                  clip_grad_norm: Optional[float] = 1.0, use_ema=True, ema_inv_gamma=1.0, ema_power=0.75,
-                 ema_max_decay=0.9999, p_uncond=0.2, bucket_mb=25, process_group=None):
+                 ema_max_decay=0.9999, p_uncond=0.2, bucket_mb=25, process_group=None, side_wgrad=None):
         self.model, self.scheduler = model, scheduler
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.clip = float(clip_grad_norm) if clip_grad_norm else 0.0
         self.p_uncond = p_uncond
+        self.side_wgrad = side_wgrad
         self.ema_cfg = (ema_inv_gamma, ema_power, ema_max_decay)
         self.arena = FlatArena(model)
         dev = self.arena.data.device
@@ -80,6 +81,9 @@ class TrainStep:
         self._init_weight_mirrors()
         self.reducer = BucketedAllReduce(self.arena.grad, self.arena.offsets, bucket_mb << 20, process_group)
         self.world = self.reducer.world
+        if self.side_wgrad is None:
+            # with data parallelism the bucket all-reduces already overlap backward and order against one stream
+            self.side_wgrad = self.world == 1
         self._in_backward = False
         self._param_index = {id(p): i for i, (_, p) in enumerate(self.arena.params)}
         if self.world > 1:
@@ -154,11 +158,15 @@ class TrainStep:
         self.reducer.begin()
         self._in_backward = True
         ops.DIRECT_GRADS, ops.GRAD_READY = True, (self._on_grad_ready if self.world > 1 else None)
+        ops.SIDE_WGRAD = self.side_wgrad
         try:
             loss.backward()
         finally:
-            ops.DIRECT_GRADS, ops.GRAD_READY = False, None
+            ops.DIRECT_GRADS, ops.GRAD_READY, ops.SIDE_WGRAD = False, None, False
             self._in_backward = False
+        if self.side_wgrad:
+            # the weight/bias gradient kernels ran on the second stream: join before anything reads the arena
+            torch.cuda.current_stream().wait_stream(ops.side_stream(self.arena.data.device))
         self.reducer.finish()
         a = self.arena
         st = torch.cuda.current_stream().cuda_stream
