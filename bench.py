@@ -148,8 +148,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--no-side-stream", action="store_true",
-                    help="keep the weight-gradient kernels on the main stream instead of overlapping them on a second one")
+    ap.add_argument("--side-streams", type=int, default=None,
+                    help="streams the weight-gradient kernels rotate over beside the main one (0: none; default: the harness's)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -165,8 +165,8 @@ def main():
     cfg = load_cfg(args.config)
     batch = args.batch or cfg["batch_size"]
     model, sched, step = build_step(cfg, device)
-    if args.no_side_stream:
-        step.side_wgrad = False
+    if args.side_streams is not None:
+        step.side_wgrad = args.side_streams
     x, cls = synthetic_batch(cfg, rank, device, batch)
 
     from dm_hip import ops
@@ -222,7 +222,7 @@ def main():
     # dominant-kernel roofline from one instrumented eager step
     roof = None
     if rank == 0:
-        step.side_wgrad = False  # time every launch alone on one stream
+        step.side_wgrad = 0  # time every launch alone on one stream
         with ConvTimer() as ct:
             step.step(x, cls)
         s = ct.summary()

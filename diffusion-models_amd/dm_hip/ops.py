@@ -29,15 +29,21 @@ GRAD_READY = None
 # they depend only on tensors that exist when a layer's backward starts and nothing but the optimizer reads their
 # results, so they overlap the data-gradient / GroupNorm chain. Whoever sets it must make the consumer of the
 # gradients wait for side_stream(device).
-SIDE_WGRAD = False
+SIDE_WGRAD = 0   # number of side streams to rotate over (0: off)
 _SIDE = {}
+_SIDE_NEXT = 0
 
 
-def side_stream(device):
-    s = _SIDE.get(device)
+def side_stream(device, index=0):
+    s = _SIDE.get((device, index))
     if s is None:
-        s = _SIDE[device] = torch.cuda.Stream(device=device)
+        s = _SIDE[(device, index)] = torch.cuda.Stream(device=device)
     return s
+
+
+def side_streams(device):
+    """Every side stream created so far on `device` (the streams a consumer of the gradients must wait for)."""
+    return [s for (d, _), s in _SIDE.items() if d == device]
 
 
 def _stream():
@@ -205,7 +211,9 @@ class _ConvFn(Function):
         on_side = SIDE_WGRAD and (wsink is not None or not ctx.needs_input_grad[2]) and (bsink is not None or not want_db)
         st_w = st
         if on_side:
-            side = side_stream(dy.device)
+            global _SIDE_NEXT
+            side = side_stream(dy.device, _SIDE_NEXT % SIDE_WGRAD)
+            _SIDE_NEXT += 1
             side.wait_stream(torch.cuda.current_stream())  # dy (and the saved inputs) are complete
             st_w = side.cuda_stream
             for t in (dy, x1, x2):

@@ -83,7 +83,7 @@ class TrainStep:
         self.world = self.reducer.world
         if self.side_wgrad is None:
             # with data parallelism the bucket all-reduces already overlap backward and order against one stream
-            self.side_wgrad = self.world == 1
+            self.side_wgrad = 1 if self.world == 1 else 0
         self._in_backward = False
         self._param_index = {id(p): i for i, (_, p) in enumerate(self.arena.params)}
         if self.world > 1:
@@ -158,15 +158,16 @@ class TrainStep:
         self.reducer.begin()
         self._in_backward = True
         ops.DIRECT_GRADS, ops.GRAD_READY = True, (self._on_grad_ready if self.world > 1 else None)
-        ops.SIDE_WGRAD = self.side_wgrad
+        ops.SIDE_WGRAD = int(self.side_wgrad)
         try:
             loss.backward()
         finally:
-            ops.DIRECT_GRADS, ops.GRAD_READY, ops.SIDE_WGRAD = False, None, False
+            ops.DIRECT_GRADS, ops.GRAD_READY, ops.SIDE_WGRAD = False, None, 0
             self._in_backward = False
         if self.side_wgrad:
             # the weight/bias gradient kernels ran on the second stream: join before anything reads the arena
-            torch.cuda.current_stream().wait_stream(ops.side_stream(self.arena.data.device))
+            for side in ops.side_streams(self.arena.data.device):
+                torch.cuda.current_stream().wait_stream(side)
         self.reducer.finish()
         a = self.arena
         st = torch.cuda.current_stream().cuda_stream
