@@ -204,6 +204,155 @@ __global__ __launch_bounds__(NT) void edge_wgrad_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same gradients on the matrix cores, for feature widths 64 / 128 and image widths that are multiples of 8:
+//   D[cb][k] += sum_m big[m][cb] * S[m][k]     (k = (cs, tap), plus a column of ones for the in_conv bias)
+// is a skinny GEMM with the pixels as reduction axis. Per 64-pixel step the feature rows go to LDS as they lie in
+// memory ([pixel][cb], 32-byte units XOR-swizzled by row) and are read with the transposing ds_read_b64_tr_b16;
+// S is built k-major ([k][pixel], bf16 - the precision the image side has under autocast) so its fragments are
+// plain 16-byte reads. One workgroup = 4 waves x (Cb/4 feature channels) over a run of pixels; fp32 atomics at the end.
+template <int CS, int CB>
+__global__ __launch_bounds__(NT) void edge_wgrad_mfma_kernel(const float* __restrict__ small, const bf16_t* __restrict__ big,
+                                                             float* __restrict__ dw, float* __restrict__ dbias, int B, int H,
+                                                             int W, int big_is_output, int pix_per_block) {
+  constexpr int K = CS * 9;
+  constexpr int NTILE = (K + 1 + 15) / 16;      // 16-column tiles of D
+  constexpr int MI = CB / 64;                   // 16-row tiles per wave
+  constexpr int PPR = CB / 8, ROWB = CB * 2;    // 16-byte pieces / bytes per feature row
+  constexpr int SP = 72;                        // pitch of an S row in elements (64 pixels + 8: bank spread)
+  __shared__ __attribute__((aligned(16))) char sbig[64 * ROWB];
+  __shared__ __attribute__((aligned(16))) bf16_t sS[NTILE * 16 * SP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sg = big_is_output ? 1 : -1;
+  const int HW = H * W, M = B * HW;
+  const int m_begin = blockIdx.x * pix_per_block;
+  const int m_end = min(M, m_begin + pix_per_block);
+  auto swz = [](int row) { return PPR == 16 ? (((row & 3) | ((row >> 1) & 4)) << 1) : ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1); };
+
+  f32x4_t acc[MI][NTILE];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NTILE; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses (as in the conv weight-gradient kernel)
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  int a_off[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int colbase = wave * (CB / 4) + i * 16;
+    const int piece = (colbase >> 3) + (p >> 1);
+    const int r0 = 8 * g + q;
+    a_off[i] = r0 * ROWB + ((piece ^ swz(r0)) << 4) + (p & 1) * 8;
+  }
+
+  for (int m0 = m_begin; m0 < m_end; m0 += 64) {
+    __syncthreads();
+    // feature rows -> LDS
+    for (int i = tid; i < 64 * PPR; i += NT) {
+      const int row = i / PPR, slot = i - row * PPR;
+      const int m = m0 + row;
+      s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (m < m_end) v = *(const s16x8_t*)(big + (size_t)m * CB + 8 * slot);
+      *(s16x8_t*)(sbig + row * ROWB + ((slot ^ swz(row)) << 4)) = v;
+    }
+    // S, k-major: one thread = 8 consecutive pixels (one image row segment) of one k
+    for (int i = tid; i < NTILE * 16 * 8; i += NT) {
+      const int k = i >> 3, pg = i & 7;
+      const int m = m0 + 8 * pg;
+      bf16_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
+      if (m < m_end) {
+        if (k == K) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (bf16_t)1.f;
+        } else if (k < K) {
+          const int cs = k / 9, tap = k - cs * 9, kh = tap / 3, kw = tap - kh * 3;
+          const int b = m / HW, r = m - b * HW, h = r / W, x0 = r - h * W;
+          const int ih = h + sg * (kh - 1), iw0 = x0 + sg * (kw - 1);
+          if (ih >= 0 && ih < H) {
+            const float* src = small + ((size_t)b * CS + cs) * HW + ih * W;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int iw = iw0 + j;
+              if (iw >= 0 && iw < W) v[j] = (bf16_t)src[iw];
+            }
+          }
+        }
+      }
+      *(bf16x8_t*)(sS + k * SP + 8 * pg) = *(const bf16x8_t*)v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t af[MI], bfr[NTILE];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const char* p0 = sbig + a_off[i] + kk * 32 * ROWB;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 4 * ROWB));
+        af[i] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int j = 0; j < NTILE; ++j) bfr[j] = *(const bf16x8_t*)(sS + (j * 16 + li) * SP + kk * 32 + 8 * g);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // D: lane holds column k = 16 j + (lane & 15), rows cb = wave * CB/4 + 16 i + 4 (lane >> 4) + r
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NTILE; ++j) {
+      const int k = j * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cb = wave * (CB / 4) + i * 16 + g * 4 + r;
+        if (k < K) {
+          const int cs = k / 9, tap = k - cs * 9;
+          const size_t o = big_is_output ? ((size_t)(cb * CS + cs) * 9 + tap) : ((size_t)(cs * CB + cb) * 9 + tap);
+          atomicAdd(dw + o, acc[i][j][r]);
+        } else if (k == K && big_is_output && dbias) {
+          atomicAdd(dbias + cb, acc[i][j][r]);
+        }
+      }
+    }
+  if (!big_is_output && dbias) {
+    // out_conv bias: sum of the image-side gradient itself
+    __shared__ float red[4 * CS];
+    float part[CS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) part[cs] = 0.f;
+    for (int m = m_begin + tid; m < m_end; m += NT) {
+      const int b = m / HW, r = m - b * HW;
+#pragma unroll
+      for (int cs = 0; cs < CS; ++cs) part[cs] += small[((size_t)b * CS + cs) * HW + r];
+    }
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+      const float t = dm_wave_sum(part[cs]);
+      if (lane == 0) red[wave * CS + cs] = t;
+    }
+    __syncthreads();
+    if (tid < CS) atomicAdd(dbias + tid, red[tid] + red[CS + tid] + red[2 * CS + tid] + red[3 * CS + tid]);
+  }
+}
+
+template <int CS>
+void launch_edge_wgrad_mfma(const float* small, const bf16_t* big, float* dw, float* dbias, int B, int H, int W, int Cb,
+                            int big_is_output, hipStream_t st) {
+  const int M = B * H * W;
+  int ppb = 512;
+  while (ppb > 64 && dm_cdiv(M, ppb) < 256) ppb /= 2;
+  dim3 grid(dm_cdiv(M, ppb)), block(NT);
+  if (Cb == 128) hipLaunchKernelGGL((edge_wgrad_mfma_kernel<CS, 128>), grid, block, 0, st, small, big, dw, dbias, B, H, W, big_is_output, ppb);
+  else hipLaunchKernelGGL((edge_wgrad_mfma_kernel<CS, 64>), grid, block, 0, st, small, big, dw, dbias, B, H, W, big_is_output, ppb);
+}
+
 int check_edge(const char* who, int B, int Cs, int H, int W, int Cb) {
   DM_REQUIRE(B > 0 && H > 0 && W > 0, DM_ERR_SHAPE, "%s: empty tensor", who);
   DM_REQUIRE(Cs >= 1 && Cs <= MAXCS, DM_ERR_UNSUPPORTED, "%s: image side has %d channels (max %d)", who, Cs, MAXCS);
@@ -258,6 +407,18 @@ extern "C" int dm_edge_conv_wgrad(const float* small, const void* big, float* dw
   if (rc) return rc;
   DM_REQUIRE(small && big && dw, DM_ERR_ARG, "dm_edge_conv_wgrad: null argument");
   DM_REQUIRE(Cb <= 256, DM_ERR_UNSUPPORTED, "dm_edge_conv_wgrad: feature width %d > 256", Cb);
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* bg = (const bf16_t*)big;
+  if ((Cb == 64 || Cb == 128) && W % 8 == 0) {
+    switch (Cs) {
+      case 1: launch_edge_wgrad_mfma<1>(small, bg, dw, dbias, B, H, W, Cb, big_is_output, st); break;
+      case 2: launch_edge_wgrad_mfma<2>(small, bg, dw, dbias, B, H, W, Cb, big_is_output, st); break;
+      case 3: launch_edge_wgrad_mfma<3>(small, bg, dw, dbias, B, H, W, Cb, big_is_output, st); break;
+      default: launch_edge_wgrad_mfma<4>(small, bg, dw, dbias, B, H, W, Cb, big_is_output, st); break;
+    }
+    DM_CHECK_LAUNCH();
+    return DM_OK;
+  }
   const int M = B * H * W;
   int ppb = 1024;
   while (ppb > WG_PIX && dm_cdiv(M, ppb) < 128) ppb /= 2;
@@ -265,8 +426,6 @@ extern "C" int dm_edge_conv_wgrad(const float* small, const void* big, float* dw
   const int lds = (WG_PIX * kp + WG_PIX * Cb) * 4;
   DM_REQUIRE(lds <= 65536, DM_ERR_UNSUPPORTED, "dm_edge_conv_wgrad: feature width %d exceeds 64 KiB of LDS", Cb);
   dim3 grid(dm_cdiv(M, ppb)), block(NT);
-  hipStream_t st = (hipStream_t)stream;
-  const bf16_t* bg = (const bf16_t*)big;
   switch (Cs) {
     case 1: hipLaunchKernelGGL(edge_wgrad_kernel<1>, grid, block, lds, st, small, bg, dw, dbias, B, H, W, Cb, big_is_output, ppb); break;
     case 2: hipLaunchKernelGGL(edge_wgrad_kernel<2>, grid, block, lds, st, small, bg, dw, dbias, B, H, W, Cb, big_is_output, ppb); break;
