@@ -261,7 +261,7 @@ def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0):
 # ------------------------------------------------------------------------------------------------------------
 class _GroupNormActFn(Function):
     @staticmethod
-    def forward(ctx, x1, x2, gamma, beta, ss, pre, G, eps, act):
+    def forward(ctx, x1, x2, gamma, beta, ss, pre, G, eps, act, fork):
         _require_device(x1, "group_norm")
         x1 = as_nhwc(x1)
         x2 = as_nhwc(x2) if x2 is not None else None
@@ -286,15 +286,36 @@ class _GroupNormActFn(Function):
         ctx.save_for_backward(x1, x2, g32, b32, ss32, pre32, mean, rstd)
         ctx.params = (gamma, beta)
         ctx.cfg = (d, B, C1, C2, H, W)
+        if fork:
+            # Hand the inputs out again for a second consumer (the residual branch): its gradient then arrives here
+            # and is added inside the backward kernel instead of by a separate accumulation pass.
+            return y, x1.view_as(x1), (x2.view_as(x2) if x2 is not None else None)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, da1=None, da2=None):
         x1, x2, g32, b32, ss32, pre32, mean, rstd = ctx.saved_tensors
         d, B, C1, C2, H, W = ctx.cfg
         C = C1 + C2
+        dev = x1.device
+        if dy is None:
+            dy = torch.zeros((B, C, H, W), dtype=BF16, device=dev).contiguous(memory_format=CL)
         dy = as_nhwc(dy)
-        dev = dy.device
+        dextra = None
+        if da1 is not None or da2 is not None:
+            if x2 is None:
+                dextra = as_nhwc(da1)
+            else:
+                if da1 is None:
+                    da1 = torch.zeros_like(x1)
+                if da2 is None:
+                    da2 = torch.zeros_like(x2)
+                full = (H * W * C, 1, W * C, C)
+                if (da1.dtype == BF16 and da2.dtype == BF16 and da1.stride() == full and da2.stride() == full
+                        and da2.data_ptr() == da1.data_ptr() + 2 * C1):
+                    dextra = da1  # the two gradients are the channel slices of one dense [B][HW][C] buffer
+                else:
+                    dextra = as_nhwc(torch.cat([da1, da2], dim=1))
         dx1 = empty_nhwc(B, C1, H, W, dev)
         dx2 = empty_nhwc(B, C2, H, W, dev) if x2 is not None else None
         gs, bs = _grad_sink(ctx.params[0]), _grad_sink(ctx.params[1])
@@ -309,18 +330,20 @@ class _GroupNormActFn(Function):
         st = _stream()
         ws = _gn_workspace(dev, 3 * B * C + B)
         check(lib.dm_groupnorm_act_bwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
-                                       _p(ss32), _p(pre32), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), None,
-                                       dx1.data_ptr(), _p(dx2), dg.data_ptr(), db_.data_ptr(), _p(dss),
+                                       _p(ss32), _p(pre32), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(),
+                                       _p(dextra), dx1.data_ptr(), _p(dx2), dg.data_ptr(), db_.data_ptr(), _p(dss),
                                        _p(dpre), ws.data_ptr(), st))
         if direct:
             _grad_done(ctx.params[0])
             _grad_done(ctx.params[1])
-            return dx1, dx2, None, None, dss, dpre, None, None, None
-        return dx1, dx2, dg, db_, dss, dpre, None, None, None
+            return dx1, dx2, None, None, dss, dpre, None, None, None, None
+        return dx1, dx2, dg, db_, dss, dpre, None, None, None, None
 
 
-def group_norm_act(x1, gamma, beta, groups, eps, act, x2=None, scale_shift=None, pre_add=None):
-    return _GroupNormActFn.apply(x1, x2, gamma, beta, scale_shift, pre_add, groups, eps, act)
+def group_norm_act(x1, gamma, beta, groups, eps, act, x2=None, scale_shift=None, pre_add=None, fork=False):
+    """With fork=True returns (y, x1', x2'): x1'/x2' are the inputs again, to be used by a second consumer whose
+    gradient is then folded into this operator's backward kernel."""
+    return _GroupNormActFn.apply(x1, x2, gamma, beta, scale_shift, pre_add, groups, eps, act, fork)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -78,7 +78,12 @@ class ConvBlock(nn.Module):
         x = ops.as_nhwc(x)
         skip = ops.as_nhwc(skip) if skip is not None else None
 
-        h = self._norm_act(self.norm1, x, x2=skip)
+        if is_silu(self.nonlinearity):
+            # the residual branch reads x (and skip) through norm1's fork, so that its gradient is added inside
+            # norm1's backward kernel
+            h, x, skip = self.norm1(x, act=True, x2=skip, fork=True)
+        else:
+            h = self._norm_act(self.norm1, x, x2=skip)
         h = self.conv1(h)
 
         mix = {}

@@ -49,6 +49,6 @@ class GroupNorm(nn.GroupNorm):
     """GroupNorm with the following SiLU, an optional per-sample scale/shift or pre-add, and an optional
     second input tensor (channel concat) fused into one kernel."""
 
-    def forward(self, x, act: bool = False, x2=None, scale_shift=None, pre_add=None):
+    def forward(self, x, act: bool = False, x2=None, scale_shift=None, pre_add=None, fork: bool = False):
         return ops.group_norm_act(x, self.weight, self.bias, self.num_groups, self.eps, act, x2=x2,
-                                  scale_shift=scale_shift, pre_add=pre_add)
+                                  scale_shift=scale_shift, pre_add=pre_add, fork=fork)
