@@ -14,6 +14,8 @@
 // into dw, which therefore ACCUMULATES (callers zero it or keep the running gradient in it).
 #include "dm_common.h"
 
+extern int g_dm_use_wgrad3;
+
 namespace {
 
 constexpr int BKM = 64;  // pixels per step
@@ -298,6 +300,240 @@ __global__ __launch_bounds__(256 * KG, 1) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 layers whose output width divides 64: one workgroup owns a 128 (co) x 64 (ci) tile for the
+// THREE taps of one kernel row. A 64-pixel step is RS = 64 / Wo whole output rows; the input rows they need are
+// staged once WITH their left/right halo ([RS][Wo + 2] pixels) and the three taps read them at column offsets
+// 0, 1, 2, so a step moves ~26 KB into LDS for 3 x as many MFMAs as the single-tap kernel's 24 KB (the L2 -> LDS
+// path, not the matrix core, bounds these kernels). The dy fragments are shared by the three taps as well.
+// Same ring / wave-group / counted-vmcnt structure as conv_wgrad_kernel.
+template <int N>
+__device__ __forceinline__ void frag_wait_n(s16x4_t (&a)[N], s16x4_t (&b)[N]);
+template <>
+__device__ __forceinline__ void frag_wait_n<4>(s16x4_t (&a)[4], s16x4_t (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+__device__ __forceinline__ void frag_wait6(s16x4_t (&a)[6], s16x4_t (&b)[6]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]),
+                 "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]));
+}
+__device__ __forceinline__ void read_tr(s16x4_t& v, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+}
+
+template <int NST>
+__global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
+  constexpr int NT = 512, TCO = 128, TCI = 64;
+  using TY = Tile<TCO, NT>;                       // dy tile: 64 pixels x 128 channels
+  constexpr int XBYTES = 16384;                   // patch region: up to 128 pixels x 64 channels
+  constexpr int STAGE = TY::BYTES + XBYTES;
+  constexpr int XPIECES = XBYTES / 16 / NT;       // 2 per thread
+  constexpr int LPS = TY::PIECES + XPIECES;
+  constexpr int EP_PITCH = TCI + 4;
+  constexpr int EP_TAP = TCO * EP_PITCH;          // floats per tap in the epilogue buffer
+  constexpr int TOTAL = (NST * STAGE > 3 * EP_TAP * 4) ? NST * STAGE : 3 * EP_TAP * 4;
+  constexpr int MI = 4, NJ = 2;                   // wave tile 64 (co) x 32 (ci)
+  __shared__ __attribute__((aligned(16))) char smem[TOTAL];
+
+  const int per = 3 * a.n_co_tiles * a.n_ci_tiles;
+  const int logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (logical >= a.n_blocks) return;
+  const int ks = logical / per;
+  const int inner = logical - ks * per;
+  const int tiles = a.n_co_tiles * a.n_ci_tiles;
+  const int kh = inner / tiles;
+  const int rest = inner - kh * tiles;
+  const int tco = rest / a.n_ci_tiles, tci = rest - tco * a.n_ci_tiles;
+  const int co0 = tco * TCO, ci0 = tci * TCI;
+  const bool second = ci0 >= a.C1;
+  const int csrc = second ? a.C2 : a.C1;
+  const int cioff = second ? ci0 - a.C1 : ci0;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+
+  __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(second ? a.x2 : a.x1), 0,
+                                                                 second ? a.x2_bytes : a.x1_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
+
+  const int m_begin = ks * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+  const int nsteps = (m_end - m_begin + BKM - 1) / BKM;
+  const int PW = a.Wo + 2, RS = BKM / a.Wo, npatch = RS * PW;
+
+  // dy staging (as in the single-tap kernel)
+  const int yrow = tid / TY::PPR, yslot = tid % TY::PPR;
+  const int ypiece = yslot ^ swz<TY::PPR>(yrow);
+  const bool ycol_ok = co0 + ypiece * 8 < a.Cout;
+  unsigned yoff[TY::PIECES];
+#pragma unroll
+  for (int i = 0; i < TY::PIECES; ++i)
+    yoff[i] = (unsigned)(((m_begin + yrow + TY::ROW_STEP * i) * a.Cout + co0 + ypiece * 8) * 2);
+  const unsigned ystep = (unsigned)(BKM * a.Cout * 2);
+
+  // patch staging: piece idx = tid + 512 i -> patch pixel idx / 8 (row prow, column pcol incl. halo), 16-byte slot idx % 8
+  int crow[XPIECES], cbh[XPIECES];      // cursor: output row within its image, image * Hs
+  int xcol[XPIECES], xconst[XPIECES];   // source column (>> ups) or -1, channel byte offset
+  const int gr0 = m_begin / a.Wo;       // first (stacked) output row of the slice
+#pragma unroll
+  for (int i = 0; i < XPIECES; ++i) {
+    const int idx = tid + NT * i, pp = idx >> 3, slot = idx & 7;
+    const int prow = pp / PW, pcol = pp - prow * PW;
+    const int gr = gr0 + prow;
+    const int b = gr / a.Ho;
+    cbh[i] = b * a.Hs;
+    crow[i] = gr - b * a.Ho;
+    const int iw = pcol - 1;
+    xcol[i] = (pp < npatch && iw >= 0 && iw < a.Wi) ? (iw >> a.ups) : -1;
+    xconst[i] = (cioff + ((slot ^ swz<8>(pp)) << 3)) * 2;
+  }
+  const int db_hs = (RS / a.Ho) * a.Hs, dh = RS % a.Ho;
+  const int csrc2 = csrc * 2;
+  const int rows_end = (m_end + a.Wo - 1) / a.Wo;  // stacked output rows of this slice end here
+  int grow = gr0;                                  // stacked output row of patch row 0 of the next step to stage
+
+  auto stage = [&](int step) {  // called with step = 0, 1, 2, ... in order
+    char* sy = smem + (step % NST) * STAGE;
+    char* sx = sy + TY::BYTES;
+    const int mb = m_begin + step * BKM;
+#pragma unroll
+    for (int i = 0; i < TY::PIECES; ++i) {
+      const int m = mb + yrow + TY::ROW_STEP * i;
+      const unsigned off = (m < m_end && ycol_ok) ? yoff[i] : DM_OOB;
+      yoff[i] += ystep;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, DM_LDS(sy + (wave * 64 + NT * i) * 16), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < XPIECES; ++i) {
+      const int pp = (tid + NT * i) >> 3;
+      const int prow = pp / PW;
+      int ih = crow[i] - 1 + kh;
+      const bool ok = xcol[i] >= 0 && grow + prow < rows_end && ih >= 0 && ih < a.Hi;
+      ih >>= a.ups;
+      const unsigned pix = (unsigned)__umul24((unsigned)(cbh[i] + ih), (unsigned)a.Ws) + xcol[i];
+      const unsigned off = ok ? (unsigned)__umul24(pix, (unsigned)csrc2) + xconst[i] : DM_OOB;
+      crow[i] += dh;
+      const int c = crow[i] >= a.Ho;
+      crow[i] -= c ? a.Ho : 0;
+      cbh[i] += db_hs + (c ? a.Hs : 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, DM_LDS(sx + (wave * 64 + NT * i) * 16), 16, off, 0, 0, 0);
+    }
+    grow += RS;
+  };
+
+  // fragment read addresses within a stage
+  const unsigned lds_base = (unsigned)(size_t)DM_LDS(smem);
+  unsigned a_off[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a_off[i] = frag_offset<TCO>(wm * 64 + i * 16, lane) + kg * 32 * TY::ROW_BYTES;
+  // patch fragments: lane's two pixel rows (r0, r0 + 4) of this wave group's 32 pixels, per tap, per 16-channel tile
+  unsigned b_off[3][2][NJ];
+  {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = kg * 32 + 8 * g + q + 4 * h;
+      const int prow = r / a.Wo, pcol = r - prow * a.Wo;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int pp = prow * PW + pcol + t;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int piece = ((wn * 32 + j * 16) >> 3) + (p >> 1);
+          b_off[t][h][j] = TY::BYTES + pp * 128 + ((piece ^ swz<8>(pp)) << 4) + (p & 1) * 8;
+        }
+      }
+    }
+  }
+
+  f32x4_t acc[3][MI][NJ];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) stage(s);
+  // The two waves of a SIMD (one per wave group) run half a step out of phase: group 0 reads its fragments and
+  // multiplies them in the same step, group 1 multiplies the fragments it read in the previous step first and then
+  // reads the next ones, so one wave's LDS latency and address arithmetic sit under the other wave's MFMAs.
+  s16x4_t alo[MI], ahi[MI], blo[6], bhi[6];
+  auto read_frags = [&](int s) {
+    const unsigned sbase = lds_base + (unsigned)((s % NST) * STAGE);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) read_frag<0, 4 * TY::ROW_BYTES>(alo[i], ahi[i], sbase + a_off[i]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        read_tr(blo[t * 2 + j], sbase + b_off[t][0][j]);
+        read_tr(bhi[t * 2 + j], sbase + b_off[t][1][j]);
+      }
+  };
+  auto multiply = [&]() {
+    frag_wait_n<4>(alo, ahi);
+    frag_wait6(blo, bhi);
+    bf16x8_t af[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[i] = join_frag(alo[i], ahi[i]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const bf16x8_t bfr = join_frag(blo[t * 2 + j], bhi[t * 2 + j]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[t][i][j], 0, 0, 0);
+      }
+  };
+  const bool lead = __builtin_amdgcn_readfirstlane(kg) == 0;
+  for (int s = 0; s < nsteps; ++s) {
+    wait_vmcnt<LPS*(NST - 2)>();
+    // group 1's fragment reads of the previous step must have left LDS before its stage is refilled (next barrier on)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (!lead && s > 0) multiply();
+    read_frags(s);
+    stage(s + NST - 1);
+    if (lead) multiply();
+  }
+  if (!lead && nsteps > 0) multiply();
+
+  // ---- epilogue: sum the wave groups and transpose through LDS (one buffer per tap), then fp32 atomics
+  wait_vmcnt<0>();
+  __syncthreads();
+  float* ep = (float*)smem;
+  const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    if (kg == g) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* e = ep + t * EP_TAP + (wm * 64 + i * 16 + fq * 4 + r) * EP_PITCH + wn * 32 + j * 16 + frow;
+              *e = (g == 0) ? acc[t][i][j][r] : *e + acc[t][i][j][r];
+            }
+    }
+    __syncthreads();
+  }
+  for (int item = tid; item < 3 * TCO * TCI; item += NT) {
+    const int t = item / (TCO * TCI), r2 = item - t * (TCO * TCI);
+    const int row = r2 / TCI, col = r2 - row * TCI;
+    const int co = co0 + row, ci = ci0 + col;
+    if (co < a.Cout)
+      atomicAdd(a.dw + ((size_t)co * 9 + kh * 3 + t) * a.Cin + ci, ep[t * EP_TAP + row * EP_PITCH + col]);
+  }
+}
+
 void make_magic(unsigned d, unsigned& magic, unsigned& shift) {
   unsigned s = 0;
   while ((1ull << s) < d) ++s;
@@ -341,12 +577,14 @@ extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void
   a.dh_step = (BKM % (d->Ho * d->Wo)) / d->Wo;
   a.dw_step = (BKM % (d->Ho * d->Wo)) % d->Wo;
 
+  const bool row3 = g_dm_use_wgrad3 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Wo >= 8 &&
+                    BKM % d->Wo == 0 && M % BKM == 0 && (BKM / d->Wo) * (d->Wo + 2) <= 128;
   const bool wide_co = d->Cout % 128 == 0;
   const bool wide_ci = d->C1 % 128 == 0 && d->C2 % 128 == 0;
-  const int tco = wide_co ? 128 : 64, tci = wide_ci ? 128 : 64;
+  const int tco = (wide_co || row3) ? 128 : 64, tci = (wide_ci && !row3) ? 128 : 64;
   a.n_co_tiles = dm_cdiv(d->Cout, tco);
   a.n_ci_tiles = a.Cin / tci;
-  const int per = d->KH * d->KW * a.n_co_tiles * a.n_ci_tiles;
+  const int per = (row3 ? 3 : d->KH * d->KW) * a.n_co_tiles * a.n_ci_tiles;
   // One workgroup per CU: split the pixel axis so that one round of workgroups covers the chip (every further
   // split adds a full partial tile of fp32 atomics per workgroup), but keep >= 8 steps per workgroup.
   const int steps_total = dm_cdiv(M, BKM);
@@ -370,7 +608,8 @@ extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void
   a.n_blocks = a.splitk * per;
   dim3 grid((a.n_blocks + 7) / 8 * 8), block(512);
   hipStream_t st = (hipStream_t)stream;
-  if (wide_co && wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2>), grid, block, 0, st, a);
+  if (row3) hipLaunchKernelGGL((conv_wgrad3_kernel<4>), grid, block, 0, st, a);
+  else if (wide_co && wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2>), grid, block, 0, st, a);
   else if (wide_co) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 4, 2>), grid, block, 0, st, a);
   else if (wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, 2>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 4, 2>), grid, block, 0, st, a);

@@ -62,10 +62,12 @@ CONV_CASES += [
 def test_conv2d_fwd_bwd(B, C1, C2, Cout, H, W, k, stride, ups, patch):
     from dm_hip import ops, lib
     lib.dm_config_set(b"conv_patch", patch)
+    lib.dm_config_set(b"wgrad_row3", patch)   # patch=0 also selects the single-tap weight-gradient kernel
     try:
         _conv2d_case(B, C1, C2, Cout, H, W, k, stride, ups)
     finally:
         lib.dm_config_set(b"conv_patch", 1)
+        lib.dm_config_set(b"wgrad_row3", 1)
 
 
 def _conv2d_case(B, C1, C2, Cout, H, W, k, stride, ups):
