@@ -179,69 +179,125 @@ __global__ __launch_bounds__(NT) void linear_group_fwd_kernel(const float* __res
   }
 }
 
-// dx[m][k] += f'(x[m][k]) * sum_n dy_p[m][n] w_p[n][k]; grid (k tiles, m tiles, layers), dx zeroed by the caller
+// Backward of the grouped linear as two register-tiled fp32 GEMMs (the layers differ only in N, so the launch grid
+// walks 64-wide slices of all layers' N axes: item.tile0 = first slice of a layer).
+constexpr int GT_M = 128, GT_K = 128, GT_N = 64;   // tile of rows (batch), input features, slice of output features
+constexpr int GT_PITCH = GT_M + 4;
+constexpr int GT_XN = 256;   // output features one workgroup of the input-gradient kernel covers (4 slices)
+
+// dx[m][k] += f'(x[m][k]) * sum_{n in slice} dy_p[m][n] w_p[n][k]   (atomics: one partial per slice; dx zeroed by the caller)
 __global__ __launch_bounds__(NT) void linear_group_bwd_x_kernel(const float* __restrict__ x, const LinearGroup g,
                                                                 float* __restrict__ dx, int M, int K, int act_in) {
-  __shared__ float sdy[BX_ROWS][BX_CHUNK];
-  __shared__ float sw[BX_CHUNK][BX_COLS];
-  const LinearGroupItem it = g.it[blockIdx.z];
+  __shared__ __attribute__((aligned(16))) float sdy[GT_N * GT_PITCH];  // [n][m], transposed
+  __shared__ __attribute__((aligned(16))) float sw[GT_N * GT_K];       // [n][k]
+  const LinearGroupItem it = g.it[find_item(g, blockIdx.x)];
   const int N = it.N;
-  const int k0 = blockIdx.x * BX_COLS, m0 = blockIdx.y * BX_ROWS;
-  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
-  float acc = 0.f;
-  for (int n0 = 0; n0 < N; n0 += BX_CHUNK) {
-    __syncthreads();
-    if (threadIdx.x < BX_ROWS * BX_CHUNK) {
-      const int rr = threadIdx.x / BX_CHUNK, nn = threadIdx.x % BX_CHUNK;
-      sdy[rr][nn] = (m0 + rr < M && n0 + nn < N) ? it.dy[(size_t)(m0 + rr) * N + n0 + nn] : 0.f;
-    }
-    for (int i = threadIdx.x; i < BX_CHUNK * BX_COLS; i += NT) {
-      const int nn = i / BX_COLS, cc = i % BX_COLS;
-      sw[nn][cc] = (n0 + nn < N && k0 + cc < K) ? it.w[(size_t)(n0 + nn) * K + k0 + cc] : 0.f;
-    }
-    __syncthreads();
+  const int nb = (blockIdx.x - it.tile0) * GT_XN, m0 = blockIdx.y * GT_M, k0 = blockIdx.z * GT_K;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;   // rows ty*8.., columns tx*8..
+  float acc[8][8];
 #pragma unroll
-    for (int nn = 0; nn < BX_CHUNK; ++nn) acc += sdy[r][nn] * sw[nn][c];
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+  // a workgroup sums GT_XN / GT_N slices itself before its atomics: fewer adders per dx element
+  for (int n0 = nb; n0 < min(N, nb + GT_XN); n0 += GT_N) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < GT_M * GT_N; i += NT) {
+      const int mm = i / GT_N, nn = i - mm * GT_N;
+      sdy[nn * GT_PITCH + mm] = (m0 + mm < M && n0 + nn < N) ? it.dy[(size_t)(m0 + mm) * N + n0 + nn] : 0.f;
+    }
+    for (int i = threadIdx.x; i < GT_N * GT_K; i += NT) {
+      const int nn = i / GT_K, kk = i - nn * GT_K;
+      sw[i] = (n0 + nn < N && k0 + kk < K) ? it.w[(size_t)(n0 + nn) * K + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int nn = 0; nn < GT_N; ++nn) {
+      const f32x4_t d0 = *(const f32x4_t*)(sdy + nn * GT_PITCH + ty * 8), d1 = *(const f32x4_t*)(sdy + nn * GT_PITCH + ty * 8 + 4);
+      const f32x4_t w0 = *(const f32x4_t*)(sw + nn * GT_K + tx * 8), w1 = *(const f32x4_t*)(sw + nn * GT_K + tx * 8 + 4);
+      const float dv[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+      const float wv[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] += dv[i] * wv[j];
+    }
   }
-  const int m = m0 + r, k = k0 + c;
-  if (m < M && k < K) {
-    if (act_in) acc *= dm_silu_grad(x[(size_t)m * K + k]);
-    atomicAdd(dx + (size_t)m * K + k, acc);
+  // through LDS, 64 rows at a time, so that a wave's atomics cover 256 contiguous bytes of one dx row
+  float* ep = sdy;  // [64][GT_PITCH]
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if ((ty >> 3) == half) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ep[((ty & 7) * 8 + i) * GT_PITCH + tx * 8 + j] = acc[i][j];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * GT_K; idx += NT) {
+      const int row = idx / GT_K, col = idx - row * GT_K;
+      const int m = m0 + half * 64 + row, k = k0 + col;
+      if (m < M && k < K) {
+        float v = ep[row * GT_PITCH + col];
+        if (act_in) v *= dm_silu_grad(x[(size_t)m * K + k]);
+        atomicAdd(dx + (size_t)m * K + k, v);
+      }
+    }
   }
 }
 
-// dw_p[n][k] += sum_m dy_p[m][n] f(x[m][k]); db_p[n] += sum_m dy_p[m][n]; grid (k tiles, 4-row tiles over all layers)
+// dw_p[n][k] += sum_m dy_p[m][n] f(x[m][k]); db_p[n] += sum_m dy_p[m][n]; one workgroup owns a 64 x 128 tile of dw_p
 __global__ __launch_bounds__(NT) void linear_group_bwd_w_kernel(const float* __restrict__ x, const LinearGroup g, int M, int K,
                                                                 int act_in) {
-  __shared__ float sdy[BW_MAXM][BW_ROWS];
-  const LinearGroupItem it = g.it[find_item(g, blockIdx.y)];
+  __shared__ __attribute__((aligned(16))) float sdy[GT_N * GT_N];   // [m (64)][n (64)]
+  __shared__ __attribute__((aligned(16))) float sx[GT_N * GT_K];    // [m (64)][k (128)]
+  const LinearGroupItem it = g.it[find_item(g, blockIdx.x)];
   const int N = it.N;
-  const int k0 = blockIdx.x * BW_COLS, n0 = (blockIdx.y - it.tile0) * BW_ROWS;
-  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
-  const int k = k0 + c, n = n0 + r;
-  float acc = 0.f, bsum = 0.f;
-  for (int mb = 0; mb < M; mb += BW_MAXM) {
-    const int mc = min(BW_MAXM, M - mb);
+  const int n0 = (blockIdx.x - it.tile0) * GT_N, k0 = blockIdx.y * GT_K;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;   // rows (n) ty*4.., columns (k) tx*8..
+  float acc[4][8], bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+  for (int mb = 0; mb < M; mb += GT_N) {
     __syncthreads();
-    for (int i = threadIdx.x; i < mc * BW_ROWS; i += NT) {
-      const int mm = i / BW_ROWS, rr = i % BW_ROWS;
-      sdy[mm][rr] = (n0 + rr < N) ? it.dy[(size_t)(mb + mm) * N + n0 + rr] : 0.f;
+    for (int i = threadIdx.x; i < GT_N * GT_N; i += NT) {
+      const int mm = i / GT_N, nn = i - mm * GT_N;
+      sdy[i] = (mb + mm < M && n0 + nn < N) ? it.dy[(size_t)(mb + mm) * N + n0 + nn] : 0.f;
+    }
+    for (int i = threadIdx.x; i < GT_N * GT_K; i += NT) {
+      const int mm = i / GT_K, kk = i - mm * GT_K;
+      float v = (mb + mm < M && k0 + kk < K) ? x[(size_t)(mb + mm) * K + k0 + kk] : 0.f;
+      sx[i] = act_in ? dm_silu(v) : v;
     }
     __syncthreads();
-    if (k < K) {
 #pragma unroll 4
-      for (int mm = 0; mm < mc; ++mm) {
-        float xv = x[(size_t)(mb + mm) * K + k];
-        if (act_in) xv = dm_silu(xv);
-        acc += sdy[mm][r] * xv;
+    for (int mm = 0; mm < GT_N; ++mm) {
+      const f32x4_t d = *(const f32x4_t*)(sdy + mm * GT_N + ty * 4);
+      const f32x4_t x0 = *(const f32x4_t*)(sx + mm * GT_K + tx * 8), x1 = *(const f32x4_t*)(sx + mm * GT_K + tx * 8 + 4);
+      const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bsum[i] += d[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] += d[i] * xv[j];
       }
     }
-    if (it.db && blockIdx.x == 0 && c == 0)
-      for (int mm = 0; mm < mc; ++mm) bsum += sdy[mm][r];
   }
-  if (n < N) {
-    if (it.dw && k < K) it.dw[(size_t)n * K + k] += acc;
-    if (it.db && blockIdx.x == 0 && c == 0) it.db[n] += bsum;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty * 4 + i;
+    if (n >= N) continue;
+    if (it.dw) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + tx * 8 + j;
+        if (k < K) it.dw[(size_t)n * K + k] += acc[i][j];
+      }
+    }
+    if (it.db && blockIdx.y == 0 && tx == 0) it.db[n] += bsum[i];
   }
 }
 
@@ -485,7 +541,11 @@ extern "C" int dm_linear_group_bwd(const float* x, const dm_linear_item* items, 
   DM_REQUIRE(x && M > 0 && K > 0, DM_ERR_ARG, "dm_linear_group_bwd: bad argument");
   LinearGroup g;
   int tiles = 0;
-  int rc = fill_group(g, items, P, BW_ROWS, &tiles);
+  int rc = fill_group(g, items, P, GT_N, &tiles);
+  if (rc) return rc;
+  LinearGroup gx;
+  int xtiles = 0;
+  rc = fill_group(gx, items, P, GT_XN, &xtiles);
   if (rc) return rc;
   for (int p = 0; p < P; ++p) DM_REQUIRE(items[p].dy, DM_ERR_ARG, "dm_linear_group_bwd: layer %d has no output gradient", p);
   hipStream_t st = (hipStream_t)stream;
@@ -494,11 +554,11 @@ extern "C" int dm_linear_group_bwd(const float* x, const dm_linear_item* items, 
       dm_set_error("dm_linear_group_bwd: memset failed");
       return DM_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(linear_group_bwd_x_kernel, dim3(dm_cdiv(K, BX_COLS), dm_cdiv(M, BX_ROWS), P), dim3(NT), 0, st, x, g, dx, M,
-                       K, act_in);
+    hipLaunchKernelGGL(linear_group_bwd_x_kernel, dim3(xtiles, dm_cdiv(M, GT_M), dm_cdiv(K, GT_K)), dim3(NT), 0, st, x, gx, dx,
+                       M, K, act_in);
     DM_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(linear_group_bwd_w_kernel, dim3(dm_cdiv(K, BW_COLS), tiles), dim3(NT), 0, st, x, g, M, K, act_in);
+  hipLaunchKernelGGL(linear_group_bwd_w_kernel, dim3(tiles, dm_cdiv(K, GT_K)), dim3(NT), 0, st, x, g, M, K, act_in);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
