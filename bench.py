@@ -138,6 +138,69 @@ def cpu_baseline(cfg, budget_s=20.0, batch=16):
                                       f"{batch} (fp32, torch CPU primitives) after 1 warm-up step"}
 
 
+def bench_sampling(args, cfg, device, rank, world):
+    """Sampling throughput: every rank generates --sample-batch images per step of this bench with the config's
+    sampler (one "step" = one whole n-step sampling loop on one batch), UNet forward replayed from a HIP graph."""
+    from diffusion.sampler import get_sampler
+    from diffusion.scheduler import get_scheduler
+    from harness.generate import GraphedPredictor
+    from modeling import get_model
+    torch.manual_seed(42)
+    model = get_model(cfg["model_type"], **cfg["model_cfg"]).to(device).eval()
+    sched = get_scheduler(cfg["scheduler_type"], **cfg["scheduler_cfg"])
+    scfg = dict(cfg["sampler_cfg"])
+    if args.sample_steps is not None:
+        scfg["n_steps"] = args.sample_steps
+    sampler = get_sampler(cfg["sampler_type"], **scfg)
+    B = args.sample_batch
+    g = torch.Generator().manual_seed(42 + rank)
+    c = cfg["model_cfg"]["in_channels"]
+    hw = 28 if cfg["dataset"] == "mnist" else 32
+    z = torch.randn(B, c, hw, hw, generator=g).to(device)
+    cls = torch.randint(0, 10, (B,), generator=g).to(device)
+    pred = model.get_pred_fn(cond=cls, guidance_scale=cfg.get("guidance_scale", 1.0))
+    if not args.no_graph:
+        pred = GraphedPredictor(pred)
+
+    def run():
+        return torch.clip(sampler.sample(z, sched, pred), -1, 1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    if rank == 0:
+        n_steps = scfg["n_steps"]
+        fwd_tflop = FWD_GFLOP_PER_IMG.get(args.config, 0.0) * B * n_steps / 1e3
+        per = elapsed / args.steps
+        print(json.dumps({
+            "metric": f"sample imgs/sec @{n_steps} steps ({cfg['sampler_type']})", "value": round(B * world / per, 2),
+            "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(per * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"arg_json/{args.config}.json sampling loop, {n_steps} sampler steps, batch {B}/GPU",
+                       "parallelism": f"shard{world}", "hip_graph": not args.no_graph},
+            "unet_forward_ms": round(per * 1e3 / n_steps, 3),
+            "step_tflops_achieved": round(fwd_tflop / per, 2) if fwd_tflop else None,
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +211,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--mode", choices=["train", "sample"], default="train",
+                    help="train: the training step (the headline metric); sample: the sampling loop of the config")
+    ap.add_argument("--sample-batch", type=int, default=256, help="images per GPU per sampling batch (generation_batch_size)")
+    ap.add_argument("--sample-steps", type=int, default=None, help="sampler steps (default: the config's)")
     ap.add_argument("--side-streams", type=int, default=None,
                     help="streams the weight-gradient kernels rotate over beside the main one (0: none; default: the harness's)")
     args = ap.parse_args()
@@ -163,6 +230,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     cfg = load_cfg(args.config)
+    if args.mode == "sample":
+        return bench_sampling(args, cfg, device, rank, world)
     batch = args.batch or cfg["batch_size"]
     model, sched, step = build_step(cfg, device)
     if args.side_streams is not None:

@@ -3,15 +3,16 @@
 // HBM-bound streaming design. Every kernel walks whole pixel rows (all C channels of a pixel are contiguous, so
 // accesses are 16-byte pieces of full rows) with (sample, pixel-chunk) workgroups, i.e. thousands of independent
 // workgroups regardless of the tensor shape:
-//   forward   1. per-(sample, channel) sum and sum of squares  -> fp32 atomics into a [B][2][C] workspace
-//             2. every workgroup derives its sample's group statistics from that workspace (a few hundred
-//                flops) and streams y = act(ka[c] * x + kb[c])
-//   backward  1. per-(sample, channel) sums of du and du * xhat -> workspace
+//   forward   1. per-(sample, channel) sum and sum of squares -> a [B][2][C] workspace; one workgroup per
+//                (sample, 64 channels) walks all pixels, so the sums are plain stores in a fixed order: the
+//                forward pass is bit-reproducible
+//             2. (sample, pixel-chunk) workgroups derive their sample's group statistics from that workspace (a few
+//                hundred flops) and stream y = act(ka[c] * x + kb[c])
+//   backward  1. per-(sample, channel) sums of du, du * xhat (and xhat), same decomposition as forward 1
 //             2. group sums from the workspace, then dx streamed; the first pixel-chunk of each sample also emits
 //                the parameter-side gradients (dgamma/dbeta atomics, dscale_shift, dpre_add)
 // The second sweep of each pair re-reads a tensor that was just read, which the 256 MiB Infinity Cache serves.
-// The workspace must be zero on entry and is zero again on exit: the last workgroup of a sample to have read the
-// sums (arrival counter behind the sums) clears them, so one buffer serves every call with no memset launches.
+// The workspace is pure scratch (written before it is read in every call), so one buffer serves every call.
 // The channel axis may be the concatenation of two tensors (x1 | x2).
 #include "dm_common.h"
 
@@ -39,7 +40,6 @@ struct GnArgs {
   float* dss;
   float* dpre;
   float* ws;
-  int* cnt;  // per-sample arrival counters behind the sums
   int B, HW, C1, C2, C, G, cg, act, pch;
   float eps;
 };
@@ -62,62 +62,56 @@ struct Lanes {
   }
 };
 
-// combine per-thread partials red[tid][NV][8] over pixel lanes and add them to out[k*C + c]
+// ---- sweep 1 of both directions: one workgroup = (sample b, 64 channels starting at c0 = 64 * blockIdx.x).
+// Thread = (8-channel vector v = tid & 7, pixel lane pl = tid >> 3); every pixel contributes one 128-byte segment.
+constexpr int SL_C = 64, SL_V = SL_C / 8, SL_PL = NT / SL_V;   // 64 channels, 8 vectors, 32 pixel lanes
+
+// sums of NV per-thread 8-vectors over the 32 pixel lanes, in a fixed order, stored to out[k * C + c]
 template <int NV>
-__device__ __forceinline__ void reduce_to_global(float* red, const Lanes& L, int C, float* out) {
+__device__ __forceinline__ void slab_reduce_store(float (&part)[NV][8], float* red, int C, int c0, float* out) {
+  const int v = threadIdx.x & (SL_V - 1), pl = threadIdx.x / SL_V;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[(pl * NV + k) * SL_C + v * 8 + j] = part[k][j];
   __syncthreads();
-  for (int i = threadIdx.x; i < NV * C; i += NT) {
-    const int k = i / C, c = i - k * C;
-    const int vv = c >> 3, j = c & 7;
+  for (int i = threadIdx.x; i < NV * SL_C; i += NT) {
+    const int k = i / SL_C, cc = i - k * SL_C;
     float s = 0.f;
-    for (int q = 0; q < L.PL; ++q) s += red[((q * L.VP + vv) * NV + k) * 8 + j];
-    atomicAdd(out + (size_t)k * C + c, s);
+    for (int q = 0; q < SL_PL; ++q) s += red[(q * NV + k) * SL_C + cc];
+    if (c0 + cc < C) out[(size_t)k * C + c0 + cc] = s;
   }
 }
 
-
-// Called by every workgroup of sample b after it has read ws[b]: the last arriver clears the sums and the counter.
-__device__ __forceinline__ void release_workspace(float* ws_b, int n, int* counter) {
-  __shared__ int s_last;
-  __syncthreads();  // every thread of this workgroup is done reading
-  if (threadIdx.x == 0) s_last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (s_last) {
-    for (int i = threadIdx.x; i < n; i += NT) ws_b[i] = 0.f;
-    if (threadIdx.x == 0) *counter = 0;
-  }
-}
-
-// ---- forward sweep 1: ws[b][0][c] += sum x, ws[b][1][c] += sum x^2 over this chunk
+// ---- forward sweep 1: ws[b][0][c] = sum x, ws[b][1][c] = sum x^2
 __global__ __launch_bounds__(NT) void gn_stats_kernel(GnArgs a) {
-  __shared__ float red[NT * 2 * 8];
-  const int b = blockIdx.y, p0 = blockIdx.x * a.pch;
-  const int p1 = min(a.HW, p0 + a.pch);
-  const Lanes L(a.C);
-  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (L.active) {
-    const int c = 8 * L.v;
+  __shared__ float red[SL_PL * 2 * SL_C];
+  const int b = blockIdx.y, c0 = blockIdx.x * SL_C;
+  const int v = threadIdx.x & (SL_V - 1), pl = threadIdx.x / SL_V;
+  const int c = c0 + 8 * v;
+  float part[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
+  if (c < a.C) {
     const size_t base = (size_t)b * a.HW;
-    int p = p0 + L.pl;
-    for (; p + 3 * L.PL < p1; p += 4 * L.PL) {
-      bf16x8_t r0 = load_x(a, base + p, c), r1 = load_x(a, base + p + L.PL, c);
-      bf16x8_t r2 = load_x(a, base + p + 2 * L.PL, c), r3 = load_x(a, base + p + 3 * L.PL, c);
+    int p = pl;
+    for (; p + 3 * SL_PL < a.HW; p += 4 * SL_PL) {
+      bf16x8_t r0 = load_x(a, base + p, c), r1 = load_x(a, base + p + SL_PL, c);
+      bf16x8_t r2 = load_x(a, base + p + 2 * SL_PL, c), r3 = load_x(a, base + p + 3 * SL_PL, c);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float f0 = (float)r0[j], f1 = (float)r1[j], f2 = (float)r2[j], f3 = (float)r3[j];
-        s1[j] += (f0 + f1) + (f2 + f3);
-        s2[j] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+        part[0][j] += (f0 + f1) + (f2 + f3);
+        part[1][j] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
       }
     }
-    for (; p < p1; p += L.PL) {
+    for (; p < a.HW; p += SL_PL) {
       bf16x8_t r0 = load_x(a, base + p, c);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float f0 = (float)r0[j]; s1[j] += f0; s2[j] += f0 * f0; }
+      for (int j = 0; j < 8; ++j) { const float f0 = (float)r0[j]; part[0][j] += f0; part[1][j] += f0 * f0; }
     }
   }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { red[(threadIdx.x * 2 + 0) * 8 + j] = s1[j]; red[(threadIdx.x * 2 + 1) * 8 + j] = s2[j]; }
-  reduce_to_global<2>(red, L, a.C, a.ws + (size_t)b * 2 * a.C);
+  slab_reduce_store<2>(part, red, a.C, c0, a.ws + (size_t)b * 2 * a.C);
 }
 
 // group statistics of sample b from the channel sums (with the pre-add folded in analytically)
@@ -166,7 +160,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(GnArgs a) {
     s_ka[c] = ka;
     s_kb[c] = ka * (pv - mu) + sc * be + sh;  // u = sc * (ga * (x + pre - mu) * r + be) + sh
   }
-  release_workspace(a.ws + (size_t)b * 2 * a.C, 2 * a.C, a.cnt + b);
+  __syncthreads();
   const Lanes L(a.C);
   if (!L.active) return;
   const int c = 8 * L.v;
@@ -208,21 +202,30 @@ __device__ __forceinline__ void bwd_constants(const GnArgs& a, int b, float* s_x
   }
 }
 
-// ---- backward sweep 1: ws[b][0][c] += sum du, ws[b][1][c] += sum du*xhat, (ws[b][2][c] += sum xhat if pre-add)
+// ---- backward sweep 1: ws[b][0][c] = sum du, ws[b][1][c] = sum du*xhat, ws[b][2][c] = sum xhat
 __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(GnArgs a) {
-  __shared__ float red[NT * 3 * 8];
-  __shared__ float s_xa[MAXC], s_xb[MAXC], s_ua[MAXC], s_ub[MAXC];
-  const int b = blockIdx.y, p0 = blockIdx.x * a.pch;
-  const int p1 = min(a.HW, p0 + a.pch);
-  bwd_constants(a, b, s_xa, s_xb, s_ua, s_ub);
-  __syncthreads();
-  const Lanes L(a.C);
-  float sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (L.active) {
-    const int c = 8 * L.v;
+  __shared__ float red[SL_PL * 3 * SL_C];
+  const int b = blockIdx.y, c0 = blockIdx.x * SL_C;
+  const int v = threadIdx.x & (SL_V - 1), pl = threadIdx.x / SL_V;
+  const int c = c0 + 8 * v;
+  float part[3][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = part[2][j] = 0.f;
+  if (c < a.C) {
+    // per-channel constants: xhat = xa * x + xb, u = ua * x + ub
     float xa[8], xb[8], ua[8], ub[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { xa[j] = s_xa[c + j]; xb[j] = s_xb[c + j]; ua[j] = s_ua[c + j]; ub[j] = s_ub[c + j]; }
+    for (int j = 0; j < 8; ++j) {
+      const int cj = c + j, g = cj / a.cg;
+      const float r = a.rstd[(size_t)b * a.G + g], mu = a.mean[(size_t)b * a.G + g];
+      const float pv = a.pre ? a.pre[(size_t)b * a.C + cj] : 0.f;
+      const float sc = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + cj] : 1.f;
+      const float sh = a.ss ? a.ss[(size_t)b * 2 * a.C + a.C + cj] : 0.f;
+      xa[j] = r;
+      xb[j] = (pv - mu) * r;
+      ua[j] = sc * a.gamma[cj] * xa[j];
+      ub[j] = sc * (a.gamma[cj] * xb[j] + a.beta[cj]) + sh;
+    }
     const size_t base = (size_t)b * a.HW;
     auto acc = [&](const bf16x8_t& xr, const bf16x8_t& dr) {
 #pragma unroll
@@ -230,28 +233,22 @@ __global__ __launch_bounds__(NT) void gn_bwd_reduce_kernel(GnArgs a) {
         const float xv = (float)xr[j];
         const float xh = xa[j] * xv + xb[j];
         const float du = a.act ? (float)dr[j] * dm_silu_grad(ua[j] * xv + ub[j]) : (float)dr[j];
-        sa[j] += du;
-        sb[j] += du * xh;
-        sx[j] += xh;
+        part[0][j] += du;
+        part[1][j] += du * xh;
+        part[2][j] += xh;
       }
     };
-    int p = p0 + L.pl;
-    for (; p + L.PL < p1; p += 2 * L.PL) {
-      bf16x8_t x0 = load_x(a, base + p, c), x1 = load_x(a, base + p + L.PL, c);
+    int p = pl;
+    for (; p + SL_PL < a.HW; p += 2 * SL_PL) {
+      bf16x8_t x0 = load_x(a, base + p, c), x1 = load_x(a, base + p + SL_PL, c);
       bf16x8_t d0 = *(const bf16x8_t*)(a.dy + (base + p) * a.C + c);
-      bf16x8_t d1 = *(const bf16x8_t*)(a.dy + (base + p + L.PL) * a.C + c);
+      bf16x8_t d1 = *(const bf16x8_t*)(a.dy + (base + p + SL_PL) * a.C + c);
       acc(x0, d0);
       acc(x1, d1);
     }
-    for (; p < p1; p += L.PL) acc(load_x(a, base + p, c), *(const bf16x8_t*)(a.dy + (base + p) * a.C + c));
+    for (; p < a.HW; p += SL_PL) acc(load_x(a, base + p, c), *(const bf16x8_t*)(a.dy + (base + p) * a.C + c));
   }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    red[(threadIdx.x * 3 + 0) * 8 + j] = sa[j];
-    red[(threadIdx.x * 3 + 1) * 8 + j] = sb[j];
-    red[(threadIdx.x * 3 + 2) * 8 + j] = sx[j];
-  }
-  reduce_to_global<3>(red, L, a.C, a.ws + (size_t)b * 3 * a.C);
+  slab_reduce_store<3>(part, red, a.C, c0, a.ws + (size_t)b * 3 * a.C);
 }
 
 // ---- backward sweep 2: dx = r * (k * du - A_g - xhat * B_g) (+ dextra); parameter-side gradients from chunk 0
@@ -294,7 +291,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(GnArgs a) {
       }
     }
   }
-  release_workspace(a.ws + (size_t)b * 3 * a.C, 3 * a.C, a.cnt + b);
+  __syncthreads();
   const Lanes L(a.C);
   if (!L.active) return;
   const int c = 8 * L.v;
@@ -363,7 +360,7 @@ void fill(GnArgs& a, const dm_gn_desc* d) {
 }  // namespace
 
 extern "C" long dm_groupnorm_ws_floats(const dm_gn_desc* d) {
-  return d ? 3L * d->B * (d->C1 + d->C2) + d->B : 0;
+  return d ? 3L * d->B * (d->C1 + d->C2) : 0;
 }
 
 extern "C" int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma,
@@ -380,10 +377,9 @@ extern "C" int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const v
   a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.pre = pre_add;
   a.y = (bf16_t*)y; a.mean = mean; a.rstd = rstd; a.ws = ws;
   fill(a, d);
-  a.cnt = (int*)(ws + 3L * a.B * a.C);
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(dm_cdiv(a.HW, a.pch), a.B);
-  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(NT), 0, st, a);
+  dim3 grid(dm_cdiv(a.HW, a.pch), a.B), slabs(dm_cdiv(a.C, SL_C), a.B);
+  hipLaunchKernelGGL(gn_stats_kernel, slabs, dim3(NT), 0, st, a);
   DM_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(NT), 0, st, a);
   DM_CHECK_LAUNCH();
@@ -413,10 +409,9 @@ extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const v
   a.dx1 = (bf16_t*)dx1; a.dx2 = (bf16_t*)dx2; a.dgamma = dgamma; a.dbeta = dbeta;
   a.dss = dscale_shift; a.dpre = dpre_add; a.ws = ws;
   fill(a, d);
-  a.cnt = (int*)(ws + 3L * a.B * a.C);
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(dm_cdiv(a.HW, a.pch), a.B);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(NT), 0, st, a);
+  dim3 grid(dm_cdiv(a.HW, a.pch), a.B), slabs(dm_cdiv(a.C, SL_C), a.B);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, slabs, dim3(NT), 0, st, a);
   DM_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(NT), 0, st, a);
   DM_CHECK_LAUNCH();

@@ -112,11 +112,11 @@ _GN_WS = {}
 
 
 def _gn_workspace(device, floats):
-    """The per-device GroupNorm workspace: zero-filled once; the kernels hand it back zero-filled, so every call on
-    the device's stream shares it."""
+    """The per-device GroupNorm workspace (scratch that every call writes before reading), shared by all calls on
+    the device's stream."""
     ws = _GN_WS.get(device)
     if ws is None or ws.numel() < floats:
-        ws = torch.zeros(max(floats, 1 << 20), dtype=torch.float32, device=device)
+        ws = torch.empty(max(floats, 1 << 20), dtype=torch.float32, device=device)
         _GN_WS[device] = ws
     return ws
 
@@ -279,7 +279,7 @@ class _GroupNormActFn(Function):
         mean = torch.empty((B, G), dtype=torch.float32, device=x1.device)
         rstd = torch.empty((B, G), dtype=torch.float32, device=x1.device)
         d = GnDesc(B, H * W, C1, C2, G, eps, int(act), int(ss32 is not None), int(pre32 is not None))
-        ws = _gn_workspace(x1.device, 3 * B * C + B)
+        ws = _gn_workspace(x1.device, 3 * B * C)
         check(lib.dm_groupnorm_act_fwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
                                        _p(ss32), _p(pre32), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                        ws.data_ptr(), _stream()))
@@ -328,7 +328,7 @@ class _GroupNormActFn(Function):
         dss = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if ss32 is not None else None
         dpre = torch.empty((B, C), dtype=torch.float32, device=dev) if pre32 is not None else None
         st = _stream()
-        ws = _gn_workspace(dev, 3 * B * C + B)
+        ws = _gn_workspace(dev, 3 * B * C)
         check(lib.dm_groupnorm_act_bwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
                                        _p(ss32), _p(pre32), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(),
                                        _p(dextra), dx1.data_ptr(), _p(dx2), dg.data_ptr(), db_.data_ptr(), _p(dss),

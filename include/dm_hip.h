@@ -125,9 +125,8 @@ typedef struct dm_gn_desc {
   int has_pre; /* pre_add fp32 [B][C] present */
 } dm_gn_desc;
 
-/* fp32 elements of the caller-provided workspace `ws` both calls need (3*B*C sums + B arrival counters).
- * `ws` must be ZERO-FILLED before its first use; every call leaves it zero-filled again (the last workgroup to
- * read a sample's sums clears them), so one buffer can serve all calls issued on one stream with no memset. */
+/* fp32 elements of the caller-provided workspace `ws` both calls need (3*B*C). Pure scratch: every call writes it
+ * before reading it, so one buffer can serve all calls issued on one stream. */
 long dm_groupnorm_ws_floats(const dm_gn_desc* d);
 int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma, const float* beta,
                          const float* scale_shift, const float* pre_add, void* y, float* mean, float* rstd, float* ws,
