@@ -151,6 +151,7 @@ def bench_sampling(args, cfg, device, rank, world):
     scfg = dict(cfg["sampler_cfg"])
     if args.sample_steps is not None:
         scfg["n_steps"] = args.sample_steps
+    scfg["pbar"] = False
     sampler = get_sampler(cfg["sampler_type"], **scfg)
     B = args.sample_batch
     g = torch.Generator().manual_seed(42 + rank)
