@@ -39,6 +39,9 @@ class BucketedAllReduce:
                     self.bucket_of[i] = b
                     self.size[b] += 1
                     break
+        # Optional: a callable returning the HIP stream the collectives should be ordered after IN ADDITION to the
+        # current one (the stream the weight-gradient kernels run on); None: the current stream only.
+        self.extra_stream = None
         self.begin()
 
     def begin(self):
@@ -58,7 +61,16 @@ class BucketedAllReduce:
 
     def _launch(self, b):
         lo, hi = self.buckets[b]
-        self.handles.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        side = self.extra_stream() if self.extra_stream is not None else None
+        if side is not None:
+            # issue from the side stream after making it wait for the main one: the collective is then ordered after
+            # the gradients written on either stream, and the main stream is not held up
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                h = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            h = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.handles.append(h)
         self.launched.add(b)
 
     def finish(self):

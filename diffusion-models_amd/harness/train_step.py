@@ -82,8 +82,9 @@ class TrainStep:
         self.reducer = BucketedAllReduce(self.arena.grad, self.arena.offsets, bucket_mb << 20, process_group)
         self.world = self.reducer.world
         if self.side_wgrad is None:
-            # with data parallelism the bucket all-reduces already overlap backward and order against one stream
-            self.side_wgrad = 1 if self.world == 1 else 0
+            self.side_wgrad = 1
+        if self.world > 1 and self.side_wgrad and dev.type == "cuda":
+            self.reducer.extra_stream = lambda: ops.side_stream(dev, 0)
         self._in_backward = False
         self._param_index = {id(p): i for i, (_, p) in enumerate(self.arena.params)}
         if self.world > 1:

@@ -1,0 +1,78 @@
+"""GPU, two processes sharing the one device (gloo carries the collectives, so no second GPU is needed): the
+data-parallel training step - gradient buckets all-reduced while backward runs, weight-gradient kernels on the side
+stream - gives the same step as one process on the concatenated batch."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.parity import PKG, ROOT, TINY_CFG
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from tests.parity import det_sd_for
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diffusion.scheduler import get_scheduler
+        from harness.train_step import TrainStep
+        from modeling import get_model
+        dev = torch.device("cuda:0")
+        model = get_model("unet", **TINY_CFG)
+        model.load_state_dict(det_sd_for(model, 11))
+        model = model.to(dev).train()
+        sched = get_scheduler("beta", n_steps=1000)
+        step = TrainStep(model, sched, lr=2e-4, clip_grad_norm=1.0, use_ema=False, bucket_mb=1)
+        assert step.world == world and (world == 1 or len(step.reducer.buckets) > 2)
+        g = torch.Generator().manual_seed(5)
+        B = 8
+        x = torch.rand(B, 3, 16, 16, generator=g) * 2 - 1
+        cls = torch.randint(0, 10, (B,), generator=g)
+        mask = (torch.rand(B, generator=g) < 0.25).float()
+        eps = torch.randn(B, 3, 16, 16, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        before = step.arena.data.clone()
+        loss, gnorm = step.step_given_noise(*(v[lo:hi].to(dev) for v in (x, cls, mask, eps, t)))
+        early = len(step.reducer.launched)
+        torch.cuda.synchronize()
+        q.put((rank, float(loss), float(gnorm), (step.arena.data - before).cpu().numpy(), early))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def _run(world, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda r: r[0])
+    res = [(r, lo, n, torch.from_numpy(d), e) for r, lo, n, d, e in res]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch():
+    (_, loss1, norm1, delta1, _), = _run(1, 0)
+    two = _run(2, 29617)
+    # the full-batch loss is the mean of the two half-batch losses
+    assert abs(0.5 * (two[0][1] + two[1][1]) - loss1) < 1e-3 * abs(loss1)
+    for _, _, norm2, delta2, early in two:
+        assert abs(norm2 - norm1) < 5e-3 * norm1          # global norm of the AVERAGED gradient, on every rank
+        assert early > 0                                   # buckets went out before backward had finished
+        num = float((delta2 - delta1).norm()) / float(delta1.norm())
+        assert num < 0.1, num                              # same AdamW update (bf16 kernels, atomics: not bit-equal)
+    assert torch.equal(two[0][3], two[1][3])               # replicas stay identical
