@@ -252,3 +252,62 @@ def test_training_steps_vs_reference():
         pn = np.array([float(params[k].detach().double().norm()) for k in names])
         # one AdamW step moves every weight by at most lr; norms must track the reference to that scale
         assert np.allclose(pn, g[f"pnorm{s}"], rtol=1e-3, atol=1e-4)
+
+
+def test_full_size_batch_properties():
+    """The benchmark configuration itself (cos_cifar UNet, batch 128, 32x32): properties that need no reference.
+    Every kernel on the forward path treats samples independently and sums in a fixed order, so the output of a
+    sample must not depend - bit for bit - on which other samples share its batch or where it sits in it."""
+    from modeling import get_model
+    cfg = load_cfg("cos_cifar")
+    torch.manual_seed(0)
+    m = get_model(cfg["model_type"], **cfg["model_cfg"]).to(dev()).eval()
+    g = torch.Generator().manual_seed(1)
+    B = cfg["batch_size"]
+    x = (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).to(dev())
+    t = torch.randint(0, 1000, (B,), generator=g).to(dev())
+    c = torch.randint(0, 10, (B,), generator=g).to(dev())
+    mask = (torch.rand(B, generator=g) < 0.2).float().to(dev())
+    with torch.no_grad():
+        full = m(x, t, cls=c, uncond_mask=mask)
+        assert full.shape == (B, 3, 32, 32) and full.dtype == torch.float32 and bool(torch.isfinite(full).all())
+        # run to run
+        assert torch.equal(full, m(x, t, cls=c, uncond_mask=mask))
+        # sub-batches (ragged split: 128 = 37 + 91)
+        a = m(x[:37].contiguous(), t[:37], cls=c[:37], uncond_mask=mask[:37])
+        b = m(x[37:].contiguous(), t[37:], cls=c[37:], uncond_mask=mask[37:])
+        assert torch.equal(full[:37], a) and torch.equal(full[37:], b)
+        # permutation of the batch
+        perm = torch.randperm(B, generator=g).to(dev())
+        assert torch.equal(m(x[perm].contiguous(), t[perm], cls=c[perm], uncond_mask=mask[perm]), full[perm])
+        # a masked-out label is the same as no label for that row (padding row of the class table)
+        all_masked = m(x, t, cls=c, uncond_mask=torch.ones_like(mask))
+        assert torch.equal(all_masked, m(x, t))
+
+
+def test_full_size_training_step_invariants():
+    """One cos_cifar training step at batch 128: finite loss near the untrained value, the clip really bounds the
+    update, gradients are cleared, and the bf16 weight mirrors the optimizer maintains equal a fresh cast."""
+    from diffusion.scheduler import get_scheduler
+    from harness.train_step import TrainStep
+    from modeling import get_model
+    cfg = load_cfg("cos_cifar")
+    torch.manual_seed(0)
+    m = get_model(cfg["model_type"], **cfg["model_cfg"]).to(dev()).train()
+    sched = get_scheduler(cfg["scheduler_type"], **cfg["scheduler_cfg"])
+    step = TrainStep(m, sched, lr=cfg["lr"], clip_grad_norm=1.0, use_ema=True)
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(128, 3, 32, 32, generator=g) * 2 - 1).to(dev())
+    cls = torch.randint(0, 10, (128,), generator=g).to(dev())
+    before = step.arena.data.clone()
+    losses = [float(step.step(x, cls)) for _ in range(3)]
+    assert all(np.isfinite(l) and 0.3 < l < 3.0 for l in losses), losses
+    assert float(step.arena.grad.abs().max()) == 0.0
+    delta = (step.arena.data - before).abs().max()
+    assert 0 < float(delta) <= 3 * cfg["lr"] * 1.05          # |AdamW update| <= lr per step (plus weight decay)
+    assert torch.equal(step.w16, step.arena.data.to(torch.bfloat16))
+    # the data-gradient mirror is the transposition of the forward mirror, layer by layer
+    pack, w, o, n = step._bound[len(step._bound) // 2]
+    co, ci = w.shape[0], w.shape[1]
+    taps = n // (co * ci)
+    assert torch.equal(step.w16_t[o:o + n].view(ci, taps, co), step.w16[o:o + n].view(co, taps, ci).permute(2, 1, 0))
