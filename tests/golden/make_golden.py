@@ -326,6 +326,31 @@ def dump_train_steps():
     npz("train_steps_tiny.npz", **res)
 
 
+# ----------------------------------------------------------------------------------------------
+# 6. loss curve over 1000 training steps of the tiny model on a small structured data set. Only the recipe's
+#    parameters and the reference's losses are stored; tests/parity.py:curve_batches() rebuilds the batches.
+def dump_train_curve():
+    sys.path.insert(0, os.path.dirname(HERE))
+    from parity import CURVE, curve_batches
+    m = get_model("unet", **TINY_CFG)
+    load_det_weights(m, CURVE["weights_seed"])
+    m.train()
+    sched = get_scheduler("beta", schedule="cosine", cos_s=0.008, cos_max_beta=0.999, n_steps=1000)
+    opt = torch.optim.AdamW(m.parameters(), lr=CURVE["lr"], betas=(0.9, 0.99))
+    losses, gnorms = [], []
+    for s, (x, cls, mask, eps, t) in enumerate(curve_batches()):
+        x_t = sched.diffuse(x, t, eps)
+        loss = torch.nn.functional.mse_loss(m(x_t, t, cls=cls, uncond_mask=mask), eps)
+        loss.backward()
+        gnorms.append(float(torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)))
+        opt.step()
+        m.zero_grad()
+        losses.append(float(loss))
+        if s % 100 == 0:
+            print("  curve step", s, losses[-1], flush=True)
+    npz("train_curve_tiny.npz", loss=np.array(losses, dtype=np.float32), gnorm=np.array(gnorms, dtype=np.float32))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["configs", "schedules", "layers", "unets", "diffusion", "train"]
     if "configs" in which:
@@ -340,3 +365,5 @@ if __name__ == "__main__":
         dump_diffusion()
     if "train" in which:
         dump_train_steps()
+    if "curve" in which:
+        dump_train_curve()

@@ -28,6 +28,28 @@ TINY_ATTN_CFG = dict(TINY_CFG, down_block_types=["UNetDownBlock", "UNetAttnDownB
                      up_block_types=["UNetAttnUpBlock", "UNetUpBlock"], embedding_mixing="addition")
 
 
+# ---- loss-curve recipe (tests/golden/train_curve_tiny.npz holds the reference's losses for it) -------------
+CURVE = dict(weights_seed=900, data_seed=901, steps=1000, batch=16, n_images=64, lr=5e-4)
+
+
+def curve_batches():
+    """The 1000 (x, cls, mask, eps, t) batches of the loss-curve fixture: 64 structured 3x16x16 images (a 4x4 random
+    pattern per image, upsampled, plus a class-dependent brightness), sampled with replacement; everything from one
+    numpy RandomState so the reference and the device run see the same numbers."""
+    rs = np.random.RandomState(CURVE["data_seed"])
+    n, B = CURVE["n_images"], CURVE["batch"]
+    labels = rs.randint(0, 10, size=(n,)).astype(np.int64)
+    coarse = rs.uniform(-1, 1, size=(n, 3, 4, 4)).astype(np.float32)
+    images = np.clip(0.7 * np.kron(coarse, np.ones((1, 1, 4, 4), np.float32)) + (labels[:, None, None, None] - 4.5) / 15.0, -1, 1)
+    for _ in range(CURVE["steps"]):
+        idx = rs.randint(0, n, size=(B,))
+        mask = (rs.uniform(size=(B,)) < 0.2).astype(np.float32)
+        eps = rs.standard_normal(size=(B, 3, 16, 16)).astype(np.float32)
+        t = rs.randint(0, 1000, size=(B,)).astype(np.int64)
+        yield (torch.from_numpy(images[idx].astype(np.float32)), torch.from_numpy(labels[idx]), torch.from_numpy(mask),
+               torch.from_numpy(eps), torch.from_numpy(t))
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

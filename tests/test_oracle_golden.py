@@ -165,3 +165,20 @@ def test_train_steps():
         assert np.allclose(pn, g[f"pnorm{s}"], rtol=1e-5, atol=1e-6)
         ps = np.stack([np.pad(sd[k].flatten()[:8].numpy(), (0, max(0, 8 - sd[k].numel()))) for k in names])
         assert np.allclose(ps, g[f"psample{s}"], rtol=2e-4, atol=2e-6)
+
+
+def test_loss_curve_head():
+    """The oracle follows the reference's loss curve (first 40 of the fixture's 1000 steps; fp32 on both sides)."""
+    from itertools import islice
+    from modeling import get_model
+    from tests.parity import CURVE, curve_batches
+    g = golden("train_curve_tiny.npz")
+    m = get_model("unet", **TINY_CFG)
+    shapes = [(k, v.shape) for k, v in m.state_dict().items()]
+    vals = det_state_dict(shapes, CURVE["weights_seed"])
+    sd = {k: (T(vals[k]) if vals[k] is not None else v.clone()) for (k, _), v in zip(shapes, m.state_dict().values())}
+    opt = O.AdamWState({k: sd[k] for k in O.param_names(sd)}, lr=CURVE["lr"])
+    table = O.alpha_sq_from_beta(O.beta_cosine())
+    for s, batch in enumerate(islice(curve_batches(), 40)):
+        loss, gnorm, _ = O.train_step(sd, TINY_CFG, opt, batch, "vp", table, clip=1.0)
+        assert abs(float(loss) - float(g["loss"][s])) < 2e-3 * max(1.0, float(g["loss"][s])), s
