@@ -81,7 +81,7 @@ class ConvTimer:
             e0.record()
             rc = fn(desc, *args)
             e1.record()
-            self.records.append((name, flops, e0, e1))
+            self.records.append((name, flops, e0, e1, (d.B * d.Ho * d.Wo, d.Cout, d.C1 + d.C2, d.KH, d.stride, d.ups, d.transposed)))
             return rc
         return call
 
@@ -92,7 +92,12 @@ class ConvTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, flops, e0, e1 in self.records:
+        dump = os.environ.get("DM_BENCH_DUMP_CONVS")
+        for name, flops, e0, e1, shape in self.records:
+            if dump:
+                ms = e0.elapsed_time(e1)
+                sys.stderr.write(f"[conv] {name[11:]:6s} M={shape[0]:6d} N={shape[1]:4d} C={shape[2]:4d} k={shape[3]} s={shape[4]} "
+                                 f"ups={shape[5]} T={shape[6]} {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF\n")
             s = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
             s["launches"] += 1
             s["flops"] += flops

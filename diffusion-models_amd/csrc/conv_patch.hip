@@ -66,6 +66,24 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Fragment reads as inline asm, issued in one burst per tap step, with waits by hand (the compiler's own schedule
+// trickles the reads out between the MFMAs and waits lgkmcnt(0) half a dozen times per step).
+__device__ __forceinline__ void lds_read128(f32x4_t& v, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+}
+template <int N, int MI_, int NJ_>
+__device__ __forceinline__ void frags_wait(f32x4_t (&a)[MI_], f32x4_t (&b)[NJ_]) {
+  static_assert(MI_ == 4 && (NJ_ == 4 || NJ_ == 2), "fragment counts");
+  if constexpr (NJ_ == 4)
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(N));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1])
+                 : "n"(N));
+}
+
 template <int BN, int NP>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
   using L = Lay<BN, NP>;
@@ -168,10 +186,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
   issue_B(0, 0, 0);
   issue_B(1, 0, 1);
 
+  const unsigned lds_base = (unsigned)(size_t)DM_LDS(smem);
+  f32x4_t af[2][MI], bfr[2][NJ];  // the fragments of one tap step (both 32-channel halves)
+  auto multiply = [&]() {
+    frags_wait<MI + NJ>(af[0], bfr[0]);   // the second half's reads may still be in flight
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (kk == 1) frags_wait<0>(af[1], bfr[1]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[kk][i]),
+                                                              __builtin_bit_cast(bf16x8_t, bfr[kk][j]), acc[i][j], 0, 0, 0);
+    }
+  };
+  constexpr bool SHIFT = BN == 128;
+  const bool lead = !SHIFT || __builtin_amdgcn_readfirstlane(wave) < 4;
+
   const int nchunks = a.Cin / BK;
   for (int c = 0; c < nchunks; ++c) {
     const int cc = c * BK;
-    const char* abuf = smem + ((c & 1) ? L::A1 : L::A0);
+    const unsigned abase = lds_base + ((c & 1) ? L::A1 : L::A0);
     // keep the 72 per-tap fragment addresses from being hoisted out of this loop into registers
     int pw = a.PW;
     asm volatile("" : "+s"(pw));
@@ -179,10 +215,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
       constexpr int tap = decltype(tap_c)::value;
       // weights of this step (and everything older, i.e. this chunk's patch) have landed for this wave ...
       wait_vmcnt<younger_loads<BP, NP>(tap)>();
-      // ... and for every wave; every wave has also finished the previous step, whose weight stage is refilled next
-      asm volatile("" ::: "memory");
+      // ... and for every wave; every wave has also finished reading the previous step's weight stage (the second
+      // wave group issued those reads last thing in that step: drain them before anybody refills the stage)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      // 128-wide tiles: the two waves of a SIMD (wave groups 0-3 / 4-7) run half a step out of phase - the first
+      // group reads this step's fragments and multiplies them, the second multiplies what it read in the previous
+      // step, then reads - so one wave's LDS latency and address arithmetic sit under the other's MFMAs (measured
+      // +3..6 % inside a training step). 64-wide tiles have half the MFMAs per step to hide anything under and are
+      // faster with the plain read-then-multiply order.
+      if constexpr (SHIFT) {
+        if (!lead && !(tap == 0 && c == 0)) multiply();
+      }
       // weights two steps ahead, and one piece of the next chunk's patch
       {
         const int t2 = (tap + 2) % 9;
@@ -191,22 +236,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
       }
       const int kh = tap / 3, kw = tap - kh * 3;
       const int toff = a.transposed ? ((2 - kh) * pw + (2 - kw)) : (kh * pw + kw);
-      const char* bbuf = smem + L::B0 + (tap % 3) * L::B_BYTES;
+      if constexpr (SHIFT) {
+        const unsigned bbase = lds_base + L::B0 + (tap % 3) * L::B_BYTES;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8_t af[MI], bfr[NJ];
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const int p = pA[i] + toff;
-          af[i] = *(const bf16x8_t*)(abuf + (p << 7) + ((((kk * 4 + fq) ^ p) & 7) << 4));
+          for (int i = 0; i < MI; ++i) {
+            const int p = pA[i] + toff;
+            lds_read128(af[kk][i], abase + (p << 7) + ((((kk * 4 + fq) ^ p) & 7) << 4));
+          }
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) lds_read128(bfr[kk][j], bbase + b_off[j][kk]);
         }
+        if (lead) multiply();
+      } else {
+        const char* abuf = smem + ((c & 1) ? L::A1 : L::A0);
+        const char* bbuf = smem + L::B0 + (tap % 3) * L::B_BYTES;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bfr[j] = *(const bf16x8_t*)(bbuf + b_off[j][kk]);
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8_t a2[MI], b2[NJ];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+          for (int i = 0; i < MI; ++i) {
+            const int p = pA[i] + toff;
+            a2[i] = *(const bf16x8_t*)(abuf + (p << 7) + ((((kk * 4 + fq) ^ p) & 7) << 4));
+          }
 #pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NJ; ++j) b2[j] = *(const bf16x8_t*)(bbuf + b_off[j][kk]);
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[i], b2[j], acc[i][j], 0, 0, 0);
+        }
       }
     };
     step(std::integral_constant<int, 0>{});
@@ -219,6 +280,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
     step(std::integral_constant<int, 7>{});
     step(std::integral_constant<int, 8>{});
   }
+
+  if (SHIFT && !lead) multiply();
 
   // ---- epilogue (the trailing dummy loads must have landed before LDS is reused)
   wait_vmcnt<0>();

@@ -29,17 +29,40 @@ SHAPES = [
 ]
 
 
-def timeit(fn, iters=20):
+COLD = os.environ.get("DM_BENCH_COLD") == "1"
+_flush = None
+
+
+def timeit(fn, iters=20, warm=()):
+    """Average time of fn(). With DM_BENCH_COLD=1 every call is preceded (outside the timed span) by a sweep over a
+    768 MB buffer that evicts the caches and then by a touch of the tensors in `warm` - the state a layer finds inside
+    a training step: activations just written by the previous kernel, weights not seen since the last step."""
+    global _flush
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    if not COLD:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    if _flush is None:
+        _flush = torch.empty(768 << 20, dtype=torch.uint8, device="cuda:0")
+    total = 0.0
     for _ in range(iters):
+        _flush.zero_()
+        for t in warm:
+            t.add_(0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+        e1.record()
+        torch.cuda.synchronize()
+        total += e0.elapsed_time(e1)
+    return total / iters
 
 
 def main():
@@ -71,13 +94,14 @@ def main():
         t_f0 = t_f = t_d = t_w = float("inf")
         if "f" in which:
             lib.dm_config_set(b"conv_patch", 0)
-            t_f0 = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(d), p(x1), p(x2), p(w), None, None, p(y), st)))
+            t_f0 = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(d), p(x1), p(x2), p(w), None, None, p(y), st)), warm=[t for t in (x1, x2) if t is not None])
             lib.dm_config_set(b"conv_patch", 1)
-            t_f = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(d), p(x1), p(x2), p(w), None, None, p(y), st)))
+            t_f = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(d), p(x1), p(x2), p(w), None, None, p(y), st)),
+                         warm=[t for t in (x1, x2) if t is not None])
         if "d" in which:
-            t_d = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(dt), p(dy), None, p(wt), None, None, p(dx), st)))
+            t_d = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(dt), p(dy), None, p(wt), None, None, p(dx), st)), warm=[dy])
         if "w" in which:
-            t_w = timeit(lambda: check(lib.dm_conv2d_wgrad(ctypes.byref(d), p(x1), p(x2), p(dy), p(dw), st)))
+            t_w = timeit(lambda: check(lib.dm_conv2d_wgrad(ctypes.byref(d), p(x1), p(x2), p(dy), p(dw), st)), warm=[dy])
         for key, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
             tot[key][0] += flops
             tot[key][1] += t
