@@ -39,6 +39,7 @@ struct GnArgs {
   float* dbeta;
   float* dss;
   float* dpre;
+  float* dup;   // bias gradient of the convolution that produced x (sum of dx over samples and pixels), or null
   float* ws;
   int B, HW, C1, C2, C, G, cg, act, pch;
   float eps;
@@ -284,10 +285,12 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(GnArgs a) {
         a.dss[(size_t)b * 2 * a.C + c] = a.gamma[c] * bv + a.beta[c] * av;
         a.dss[(size_t)b * 2 * a.C + a.C + c] = av;
       }
-      if (a.dpre) {
+      if (a.dpre || a.dup) {
         const int g = c / a.cg;
         // sum over pixels of dx = r * (k * a_c - HW * A_g - B_g * sum xhat_c)
-        a.dpre[(size_t)b * a.C + c] = s_xa[c] * (sc * a.gamma[c] * av - (float)a.HW * s_A[g] - s_B[g] * wx[c]);
+        const float dxsum = s_xa[c] * (sc * a.gamma[c] * av - (float)a.HW * s_A[g] - s_B[g] * wx[c]);
+        if (a.dpre) a.dpre[(size_t)b * a.C + c] = dxsum;
+        if (a.dup) atomicAdd(a.dup + c, dxsum);
       }
     }
   }
@@ -390,7 +393,7 @@ extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const v
                                     const float* beta, const float* scale_shift, const float* pre_add,
                                     const float* mean, const float* rstd, const void* dy, const void* dextra,
                                     void* dx1, void* dx2, float* dgamma, float* dbeta, float* dscale_shift,
-                                    float* dpre_add, float* ws, void* stream) {
+                                    float* dpre_add, float* dupstream_bias, float* ws, void* stream) {
   int rc = check_desc(d, "dm_groupnorm_act_bwd");
   if (rc) return rc;
   DM_REQUIRE(x1 && gamma && beta && mean && rstd && dy && dx1 && dgamma && dbeta && ws, DM_ERR_ARG,
@@ -407,7 +410,8 @@ extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const v
   a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
   a.dy = (const bf16_t*)dy; a.dextra = (const bf16_t*)dextra;
   a.dx1 = (bf16_t*)dx1; a.dx2 = (bf16_t*)dx2; a.dgamma = dgamma; a.dbeta = dbeta;
-  a.dss = dscale_shift; a.dpre = dpre_add; a.ws = ws;
+  DM_REQUIRE(!(dupstream_bias && dextra), DM_ERR_ARG, "dm_groupnorm_act_bwd: dupstream_bias excludes dextra");
+  a.dss = dscale_shift; a.dpre = dpre_add; a.dup = dupstream_bias; a.ws = ws;
   fill(a, d);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(dm_cdiv(a.HW, a.pch), a.B), slabs(dm_cdiv(a.C, SL_C), a.B);

@@ -169,7 +169,7 @@ class _ConvFn(Function):
     """y = conv2d(cat(x1, x2) [nearest-upsampled x2 if ups], weight) + bias + res"""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, res, stride, pad, ups, pack):
+    def forward(ctx, x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad=True):
         _require_device(x1, "conv2d")
         x1 = as_nhwc(x1)
         x2 = as_nhwc(x2) if x2 is not None else None
@@ -191,7 +191,8 @@ class _ConvFn(Function):
                                   y.data_ptr(), _stream()))
         ctx.save_for_backward(x1, x2, weight)
         ctx.params = (weight, bias)
-        ctx.cfg = (stride, pad, ups, pack, bias is not None, res is not None, (B, C1, C2, Hs, Ws, Hi, Wi, Ho, Wo))
+        ctx.cfg = (stride, pad, ups, pack, bias is not None and bias_grad, res is not None,
+                   (B, C1, C2, Hs, Ws, Hi, Wi, Ho, Wo))
         return y
 
     @staticmethod
@@ -251,17 +252,19 @@ class _ConvFn(Function):
             else:
                 db = dbf
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
-        return dx1, dx2, dw, db, dres, None, None, None, None
+        return dx1, dx2, dw, db, dres, None, None, None, None, None
 
 
-def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0):
-    return _ConvFn.apply(x1, x2, weight, bias, res, stride, pad, ups, pack)
+def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0, bias_grad=True):
+    """bias_grad=False: the bias is added but its gradient is left to the consumer of the output (group_norm_act's
+    upstream_bias), which gets it for free."""
+    return _ConvFn.apply(x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad)
 
 
 # ------------------------------------------------------------------------------------------------------------
 class _GroupNormActFn(Function):
     @staticmethod
-    def forward(ctx, x1, x2, gamma, beta, ss, pre, G, eps, act, fork):
+    def forward(ctx, x1, x2, gamma, beta, ss, pre, G, eps, act, fork, upstream_bias):
         _require_device(x1, "group_norm")
         x1 = as_nhwc(x1)
         x2 = as_nhwc(x2) if x2 is not None else None
@@ -284,7 +287,7 @@ class _GroupNormActFn(Function):
                                        _p(ss32), _p(pre32), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                        ws.data_ptr(), _stream()))
         ctx.save_for_backward(x1, x2, g32, b32, ss32, pre32, mean, rstd)
-        ctx.params = (gamma, beta)
+        ctx.params = (gamma, beta, upstream_bias)
         ctx.cfg = (d, B, C1, C2, H, W)
         if fork:
             # Hand the inputs out again for a second consumer (the residual branch): its gradient then arrives here
@@ -325,6 +328,14 @@ class _GroupNormActFn(Function):
         else:
             dgb = torch.zeros((2, C), dtype=torch.float32, device=dev)
             dg, db_ = dgb[0], dgb[1]
+        # bias gradient of the convolution that produced x1 (= sum of dx), when asked for
+        ub = ctx.params[2]
+        dub = ub_sink = None
+        if ub is not None and ctx.needs_input_grad[10]:
+            if dextra is not None or x2 is not None:
+                raise RuntimeError("group_norm: upstream_bias needs a single, unforked input")
+            ub_sink = _grad_sink(ub)
+            dub = ub_sink if ub_sink is not None else torch.zeros(C, dtype=torch.float32, device=dev)
         dss = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if ss32 is not None else None
         dpre = torch.empty((B, C), dtype=torch.float32, device=dev) if pre32 is not None else None
         st = _stream()
@@ -332,18 +343,24 @@ class _GroupNormActFn(Function):
         check(lib.dm_groupnorm_act_bwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
                                        _p(ss32), _p(pre32), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(),
                                        _p(dextra), dx1.data_ptr(), _p(dx2), dg.data_ptr(), db_.data_ptr(), _p(dss),
-                                       _p(dpre), ws.data_ptr(), st))
+                                       _p(dpre), _p(dub), ws.data_ptr(), st))
+        if ub_sink is not None:
+            _grad_done(ub)
+            dub = None
         if direct:
             _grad_done(ctx.params[0])
             _grad_done(ctx.params[1])
-            return dx1, dx2, None, None, dss, dpre, None, None, None, None
-        return dx1, dx2, dg, db_, dss, dpre, None, None, None, None
+            return dx1, dx2, None, None, dss, dpre, None, None, None, None, dub
+        return dx1, dx2, dg, db_, dss, dpre, None, None, None, None, dub
 
 
-def group_norm_act(x1, gamma, beta, groups, eps, act, x2=None, scale_shift=None, pre_add=None, fork=False):
+def group_norm_act(x1, gamma, beta, groups, eps, act, x2=None, scale_shift=None, pre_add=None, fork=False,
+                   upstream_bias=None):
     """With fork=True returns (y, x1', x2'): x1'/x2' are the inputs again, to be used by a second consumer whose
-    gradient is then folded into this operator's backward kernel."""
-    return _GroupNormActFn.apply(x1, x2, gamma, beta, scale_shift, pre_add, groups, eps, act, fork)
+    gradient is then folded into this operator's backward kernel.
+    upstream_bias: the bias parameter of the convolution whose output x1 is (and that was run with bias_grad=False):
+    its gradient, the sum of dx over samples and pixels, falls out of this operator's backward sums."""
+    return _GroupNormActFn.apply(x1, x2, gamma, beta, scale_shift, pre_add, groups, eps, act, fork, upstream_bias)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -84,9 +84,10 @@ class ConvBlock(nn.Module):
             h, x, skip = self.norm1(x, act=True, x2=skip, fork=True)
         else:
             h = self._norm_act(self.norm1, x, x2=skip)
-        h = self.conv1(h)
+        # conv1's bias gradient is the sum of norm2's input gradient, which norm2's backward has at hand
+        h = self.conv1(h, bias_grad=False)
 
-        mix = {}
+        mix = {"upstream_bias": self.conv1.bias}
         if self.emb_proj is not None:
             assert embedding is not None
             e = None
@@ -99,7 +100,7 @@ class ConvBlock(nn.Module):
                 e = self.emb_proj(embedding, act_in=True)
             else:
                 e = self.emb_proj(self.nonlinearity(embedding))
-            mix = {"pre_add": e} if self.embedding_mixing == "addition" else {"scale_shift": e}
+            mix["pre_add" if self.embedding_mixing == "addition" else "scale_shift"] = e
         h = self._norm_act(self.norm2, h, **mix)
         if self.training and self.dropout.p > 0:
             h = self.dropout(h)

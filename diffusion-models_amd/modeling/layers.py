@@ -22,9 +22,10 @@ class Conv2d(nn.Conv2d):
         self._pad = (k - 1) // 2 if padding == "same" else int(self.padding[0])
         self._pack = ops.WeightPack()
 
-    def forward(self, x, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, ups: int = 0):
+    def forward(self, x, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, ups: int = 0,
+                bias_grad: bool = True):
         return ops.conv2d(x, self.weight, self.bias, self._pack, x2=x2, res=res, stride=self.stride[0],
-                          pad=self._pad, ups=ups)
+                          pad=self._pad, ups=ups, bias_grad=bias_grad)
 
 
 class Linear(nn.Linear):
@@ -49,6 +50,7 @@ class GroupNorm(nn.GroupNorm):
     """GroupNorm with the following SiLU, an optional per-sample scale/shift or pre-add, and an optional
     second input tensor (channel concat) fused into one kernel."""
 
-    def forward(self, x, act: bool = False, x2=None, scale_shift=None, pre_add=None, fork: bool = False):
+    def forward(self, x, act: bool = False, x2=None, scale_shift=None, pre_add=None, fork: bool = False,
+                upstream_bias=None):
         return ops.group_norm_act(x, self.weight, self.bias, self.num_groups, self.eps, act, x2=x2,
-                                  scale_shift=scale_shift, pre_add=pre_add, fork=fork)
+                                  scale_shift=scale_shift, pre_add=pre_add, fork=fork, upstream_bias=upstream_bias)

@@ -132,11 +132,14 @@ int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const void* x2, co
                          const float* scale_shift, const float* pre_add, void* y, float* mean, float* rstd, float* ws,
                          void* stream);
 /* dx1|dx2 bf16 (= GN backward + dextra, dextra optional bf16 [B][HW][C]); dgamma/dbeta fp32 [C] ACCUMULATE
- * (atomics); dscale_shift fp32 [B][2C] and dpre_add fp32 [B][C] are written when present */
+ * (atomics); dscale_shift fp32 [B][2C] and dpre_add fp32 [B][C] are written when present.
+ * dupstream_bias (nullable, fp32 [C], ACCUMULATES, excludes dextra): sum of dx over samples and pixels, i.e. the bias
+ * gradient of the convolution whose output x is (modeling/blocks.py:51 -> :59); it falls out of the sums this
+ * operator forms anyway, so that convolution needs no column-sum pass over dx. */
 int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma, const float* beta,
                          const float* scale_shift, const float* pre_add, const float* mean, const float* rstd,
                          const void* dy, const void* dextra, void* dx1, void* dx2, float* dgamma, float* dbeta,
-                         float* dscale_shift, float* dpre_add, float* ws, void* stream);
+                         float* dscale_shift, float* dpre_add, float* dupstream_bias, float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Spatial self-attention core. Replaces F.scaled_dot_product_attention and the view/permute/contiguous

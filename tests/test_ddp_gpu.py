@@ -57,7 +57,14 @@ def _run(world, port):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda r: r[0])
+    res = []
+    while len(res) < world:   # poll, so that a worker that died shows up at once instead of as a silent wait
+        try:
+            res.append(q.get(timeout=2))
+        except Exception:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"a worker exited with {dead}"
+    res.sort(key=lambda r: r[0])
     res = [(r, lo, n, torch.from_numpy(d), e) for r, lo, n, d, e in res]
     for p in procs:
         p.join(60)

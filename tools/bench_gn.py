@@ -50,7 +50,7 @@ def main():
                                                             p(mean), p(rstd), p(ws), st)))
         t_b = timeit(lambda: check(lib.dm_groupnorm_act_bwd(ctypes.byref(d), p(x1), p(x2), p(g), p(b), p(ss), None,
                                                             p(mean), p(rstd), p(dy), None, p(dx1), p(dx2), p(dg), p(db),
-                                                            p(dss), None, p(ws), st)))
+                                                            p(dss), None, None, p(ws), st)))
         n = B * HW * C
         tf += t_f
         tb += t_b
