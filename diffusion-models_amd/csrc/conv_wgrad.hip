@@ -595,7 +595,7 @@ extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void
   }();
   // Split the pixel axis to minimise rounds x (steps per workgroup + fixed cost): one workgroup per CU per round,
   // the fixed cost (pipeline fill, partial-tile atomics) counted as OVERHEAD steps.
-  constexpr int OVERHEAD = 7;
+  constexpr int OVERHEAD = 30;   // measured with cold caches: pipeline fill + partial-tile atomics cost about 30 steps
   const int max_split = steps_total / 8 > 0 ? (steps_total / 8 < 64 ? steps_total / 8 : 64) : 1;
   int splitk = 1;
   long best = -1;
