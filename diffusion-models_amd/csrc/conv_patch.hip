@@ -352,7 +352,9 @@ int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, con
   if (Cin % BK || d->C1 % BK) return DM_ERR_UNSUPPORTED;
   // narrow outputs on small images: 64-column tiles keep every CU busy
   const long M = (long)d->B * H * W;
-  const bool bn64 = d->Cout <= 64 || (M / BM) * dm_cdiv(d->Cout, 128) < 200;
+  // (measured with cold caches: with at most 32 row tiles, 64-column tiles win up to 1024 output channels)
+  const long mt = M / BM, blocks128 = mt * dm_cdiv(d->Cout, 128);
+  const bool bn64 = d->Cout <= 64 || blocks128 < 200 || (mt <= 32 && blocks128 <= 256);
   const int cap = bn64 ? Lay<64, 7>::PIX_CAP : Lay<128, 6>::PIX_CAP;
   const int TR = pick_rows(H, W, cap);
   if (TR <= 0 || TR * W < BM / 2) return DM_ERR_UNSUPPORTED;   // too ragged to be worth it
