@@ -16,6 +16,8 @@
 // The channel axis may be the concatenation of two tensors (x1 | x2).
 #include "dm_common.h"
 
+extern int g_dm_gn_fused;
+
 namespace {
 
 constexpr int NT = 256;
@@ -333,6 +335,277 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(GnArgs a) {
   for (; p < p1; p += L.PL) emit(load_x(a, base + p, c), *(const bf16x8_t*)(a.dy + (base + p) * a.C + c), p);
 }
 
+// ============================================================================================================
+// Single-pass kernels for the common case (channels per group divide 64, at most 1024 pixels per sample).
+// One workgroup = (sample b, 64 channels): it holds that slab of x (and dy) IN REGISTERS - 8 pixels per thread,
+// one thread per pixel lane and 8-channel vector (16 pixels for 32x32 images) - so every tensor is read from memory exactly once and the sums
+// never leave the CU: forward 4 B/element instead of 6, backward 6 (+2 with a residual gradient) instead of 10.
+// Groups never straddle the slab, so the group statistics are workgroup-local; all sums run in a fixed order.
+constexpr int FS_MAXT = 512;   // threads per workgroup (= pixel lanes * 8): 8 waves, so up to 256 registers per thread
+// pixels per thread: template parameter FS_PPT = 8 (up to 512 pixels per sample) or 16 (up to 1024)
+
+// sums of NV per-thread 8-vectors over all pixel lanes: shuffles inside a wave (lanes with equal tid & 7), then a
+// fixed-order sum over the waves through LDS. Result for channel cc (0..63), quantity k in out[k * 64 + cc].
+template <int NV>
+__device__ __forceinline__ void slab_block_sum(float (&part)[NV][8], float* red /*[waves][NV][64]*/, float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = part[k][j];
+      t += __shfl_xor(t, 8, 64);
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      part[k][j] = t;
+    }
+  if (lane < 8) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[(wave * NV + k) * 64 + lane * 8 + j] = part[k][j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV * 64; i += blockDim.x) {
+    float t = 0.f;
+    for (int w = 0; w < nw; ++w) t += red[w * NV * 64 + i];
+    out[i] = t;
+  }
+  __syncthreads();
+}
+
+template <int FS_PPT>
+__global__ __launch_bounds__(FS_MAXT) void gn_fwd_fused_kernel(GnArgs a) {
+  __shared__ float red[(FS_MAXT / 64) * 2 * 64];
+  __shared__ float sums[2 * 64];
+  __shared__ float s_mean[64], s_rstd[64];   // per group of the slab (at most 64 / cg <= 16 used... cg >= 1)
+  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int v = threadIdx.x & 7, pl = threadIdx.x >> 3, PLN = blockDim.x >> 3;
+  const int c = c0 + 8 * v;
+  const bool cok = c < a.C;
+  const size_t base = (size_t)b * a.HW;
+  bf16x8_t xr[FS_PPT];
+  float part[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < FS_PPT; ++i) {
+    const int p = pl + i * PLN;
+    if (cok && p < a.HW) xr[i] = load_x(a, base + p, c);
+    else xr[i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int i = 0; i < FS_PPT; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float f = (float)xr[i][j]; part[0][j] += f; part[1][j] += f * f; }
+  slab_block_sum<2>(part, red, sums);
+#pragma unroll
+  for (int i = 0; i < FS_PPT; ++i) asm volatile("" : "+v"(xr[i]));   // keep the slab packed (see the backward kernel)
+  // group statistics (pre-add folded in analytically)
+  const int ng = 64 / a.cg;
+  for (int gl = threadIdx.x; gl < ng; gl += blockDim.x) {
+    const int g = c0 / a.cg + gl;
+    if (g < a.G) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int j = 0; j < a.cg; ++j) {
+        const int cc = gl * a.cg + j;
+        float u1 = sums[cc], u2 = sums[64 + cc];
+        if (a.pre) {
+          const float pv = a.pre[(size_t)b * a.C + c0 + cc];
+          u2 += 2.f * pv * u1 + (float)a.HW * pv * pv;
+          u1 += (float)a.HW * pv;
+        }
+        t1 += u1;
+        t2 += u2;
+      }
+      const float inv_n = 1.0f / (float)(a.cg * a.HW);
+      const float m = t1 * inv_n;
+      const float var = fmaxf(t2 * inv_n - m * m, 0.f);
+      const float r = rsqrtf(var + a.eps);
+      s_mean[gl] = m;
+      s_rstd[gl] = r;
+      a.mean[(size_t)b * a.G + g] = m;
+      a.rstd[(size_t)b * a.G + g] = r;
+    }
+  }
+  __syncthreads();
+  if (!cok) return;
+  float ka[8], kb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int cj = c + j, gl = (cj - c0) / a.cg;
+    const float r = s_rstd[gl], mu = s_mean[gl];
+    float sc = 1.f, sh = 0.f;
+    if (a.ss) { sc = 1.f + a.ss[(size_t)b * 2 * a.C + cj]; sh = a.ss[(size_t)b * 2 * a.C + a.C + cj]; }
+    const float pv = a.pre ? a.pre[(size_t)b * a.C + cj] : 0.f;
+    ka[j] = sc * a.gamma[cj] * r;
+    kb[j] = ka[j] * (pv - mu) + sc * a.beta[cj] + sh;
+  }
+#pragma unroll
+  for (int i = 0; i < FS_PPT; ++i) {
+    const int p = pl + i * PLN;
+    if (p < a.HW) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float u = ka[j] * (float)xr[i][j] + kb[j];
+        f[j] = a.act ? dm_silu(u) : u;
+      }
+      *(bf16x8_t*)(a.y + (base + p) * a.C + c) = dm_pack8(f);
+    }
+  }
+}
+
+template <int FS_PPT>
+__global__ __launch_bounds__(FS_MAXT) void gn_bwd_fused_kernel(GnArgs a) {
+  __shared__ float red[(FS_MAXT / 64) * 3 * 64];
+  __shared__ float sums[3 * 64];
+  __shared__ float s_A[64], s_B[64];
+  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int v = threadIdx.x & 7, pl = threadIdx.x >> 3, PLN = blockDim.x >> 3;
+  const int c = c0 + 8 * v;
+  const bool cok = c < a.C;
+  const size_t base = (size_t)b * a.HW;
+  // per-channel constants in LDS (the slab itself takes up to 128 registers): xhat = xa * x + xb, u = ua * x + ub (ua = sc * gamma * r)
+  __shared__ float s_k[4][64];
+  for (int cc = threadIdx.x; cc < 64; cc += blockDim.x) {
+    const int cj = c0 + cc;
+    float kxa = 0.f, kxb = 0.f, kua = 0.f, kub = 0.f;
+    if (cj < a.C) {
+      const int g = cj / a.cg;
+      const float r = a.rstd[(size_t)b * a.G + g], mu = a.mean[(size_t)b * a.G + g];
+      const float pv = a.pre ? a.pre[(size_t)b * a.C + cj] : 0.f;
+      const float sc = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + cj] : 1.f;
+      const float sh = a.ss ? a.ss[(size_t)b * 2 * a.C + a.C + cj] : 0.f;
+      kxa = r;
+      kxb = (pv - mu) * r;
+      kua = sc * a.gamma[cj] * r;
+      kub = sc * (a.gamma[cj] * kxb + a.beta[cj]) + sh;
+    }
+    s_k[0][cc] = kxa; s_k[1][cc] = kxb; s_k[2][cc] = kua; s_k[3][cc] = kub;
+  }
+  const float* xa = &s_k[0][8 * v];
+  const float* xb = &s_k[1][8 * v];
+  const float* ua = &s_k[2][8 * v];
+  const float* ub = &s_k[3][8 * v];
+  // x stays in registers; dy is parked in LDS between the two passes (each thread reads back only what it wrote);
+  // dynamic LDS: FS_PPT * blockDim.x 16-byte slots, so small samples keep several workgroups per CU
+  extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+  bf16x8_t* s_dy = (bf16x8_t*)s_dyn;
+  bf16x8_t xr[FS_PPT];
+  {
+    bf16x8_t dr[FS_PPT];
+#pragma unroll
+    for (int i = 0; i < FS_PPT; ++i) {
+      const int p = pl + i * PLN;
+      if (cok && p < a.HW) {
+        xr[i] = load_x(a, base + p, c);
+        dr[i] = *(const bf16x8_t*)(a.dy + (base + p) * a.C + c);
+      } else {
+        xr[i] = dr[i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FS_PPT; ++i) s_dy[i * blockDim.x + threadIdx.x] = dr[i];
+  }
+  __syncthreads();   // constants visible
+  float part[3][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = part[2][j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < FS_PPT; ++i) {
+    const bool pok = pl + i * PLN < a.HW;
+    const bf16x8_t dri = s_dy[i * blockDim.x + threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xv = (float)xr[i][j];
+      const float xh = xa[j] * xv + xb[j];
+      const float du = a.act ? (float)dri[j] * dm_silu_grad(ua[j] * xv + ub[j]) : (float)dri[j];
+      part[0][j] += du;
+      part[1][j] += du * xh;
+      part[2][j] += pok ? xh : 0.f;
+    }
+  }
+  slab_block_sum<3>(part, red, sums);
+  // keep the slab PACKED across the reduction: without this the compiler carries the unpacked floats of the first
+  // pass (128 registers) into the second and spills
+#pragma unroll
+  for (int i = 0; i < FS_PPT; ++i) asm volatile("" : "+v"(xr[i]));
+  const float inv_n = 1.0f / (float)(a.cg * a.HW);
+  const int ng = 64 / a.cg;
+  for (int gl = threadIdx.x; gl < ng; gl += blockDim.x) {
+    float A = 0.f, Bv = 0.f;
+    for (int j = 0; j < a.cg; ++j) {
+      const int cc = gl * a.cg + j, cj = c0 + cc;
+      if (cj < a.C) {
+        const float k = a.gamma[cj] * (a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + cj] : 1.f);
+        A += k * sums[cc];
+        Bv += k * sums[64 + cc];
+      }
+    }
+    s_A[gl] = A * inv_n;
+    s_B[gl] = Bv * inv_n;
+  }
+  __syncthreads();
+  // parameter-side gradients of this slab's channels
+  for (int cc = threadIdx.x; cc < 64; cc += blockDim.x) {
+    const int cj = c0 + cc;
+    if (cj < a.C) {
+      const float av = sums[cc], bv = sums[64 + cc], xs = sums[128 + cc];
+      const float sc = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + cj] : 1.f;
+      atomicAdd(a.dbeta + cj, sc * av);
+      atomicAdd(a.dgamma + cj, sc * bv);
+      if (a.dss) {
+        a.dss[(size_t)b * 2 * a.C + cj] = a.gamma[cj] * bv + a.beta[cj] * av;
+        a.dss[(size_t)b * 2 * a.C + a.C + cj] = av;
+      }
+      if (a.dpre || a.dup) {
+        const int gl = cc / a.cg, g = cj / a.cg;
+        const float r = a.rstd[(size_t)b * a.G + g];
+        const float dxsum = r * (sc * a.gamma[cj] * av - (float)a.HW * s_A[gl] - s_B[gl] * xs);
+        if (a.dpre) a.dpre[(size_t)b * a.C + cj] = dxsum;
+        if (a.dup) atomicAdd(a.dup + cj, dxsum);
+      }
+    }
+  }
+  if (!cok) return;
+  float Ag[8], Bg[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const int gl = (c + j - c0) / a.cg; Ag[j] = s_A[gl]; Bg[j] = s_B[gl]; }
+#pragma unroll
+  for (int i = 0; i < FS_PPT; ++i) {
+    const int p = pl + i * PLN;
+    if (p < a.HW) {
+      const size_t o = (base + p) * a.C + c;
+      float f[8], e[8];
+      if (a.dextra) dm_unpack8(*(const bf16x8_t*)(a.dextra + o), e);
+      const bf16x8_t dri = s_dy[i * blockDim.x + threadIdx.x];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xv = (float)xr[i][j];
+        const float xh = xa[j] * xv + xb[j];
+        const float du = a.act ? (float)dri[j] * dm_silu_grad(ua[j] * xv + ub[j]) : (float)dri[j];
+        const float dxv = ua[j] * du - xa[j] * (Ag[j] + xh * Bg[j]);
+        f[j] = a.dextra ? dxv + e[j] : dxv;
+      }
+      const bf16x8_t ov = dm_pack8(f);
+      if (c < a.C1) *(bf16x8_t*)(a.dx1 + (base + p) * a.C1 + c) = ov;
+      else *(bf16x8_t*)(a.dx2 + (base + p) * a.C2 + (c - a.C1)) = ov;
+    }
+  }
+}
+
+// the single-pass kernels cover this descriptor? (backward: 8 pixels per thread only - with 16 the slab no longer
+// fits the register file beside the arithmetic)
+bool fused_ok(const GnArgs& a, bool backward) {
+  return g_dm_gn_fused && a.cg <= 64 && 64 % a.cg == 0 && a.HW <= FS_MAXT / 8 * (backward ? 8 : 16);
+}
+int fused_ppt(const GnArgs& a) { return a.HW > FS_MAXT / 8 * 8 ? 16 : 8; }
+int fused_threads(const GnArgs& a) {   // one thread per (pixel lane, 8-channel vector)
+  const int lanes = dm_cdiv(a.HW, fused_ppt(a));
+  return dm_cdiv(lanes * 8, 64) * 64;
+}
+
 int check_desc(const dm_gn_desc* d, const char* who) {
   DM_REQUIRE(d, DM_ERR_ARG, "%s: null descriptor", who);
   const int C = d->C1 + d->C2;
@@ -381,6 +654,12 @@ extern "C" int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const v
   a.y = (bf16_t*)y; a.mean = mean; a.rstd = rstd; a.ws = ws;
   fill(a, d);
   hipStream_t st = (hipStream_t)stream;
+  if (fused_ok(a, false)) {
+    if (fused_ppt(a) == 16) hipLaunchKernelGGL(gn_fwd_fused_kernel<16>, dim3(dm_cdiv(a.C, 64), a.B), dim3(fused_threads(a)), 0, st, a);
+    else hipLaunchKernelGGL(gn_fwd_fused_kernel<8>, dim3(dm_cdiv(a.C, 64), a.B), dim3(fused_threads(a)), 0, st, a);
+    DM_CHECK_LAUNCH();
+    return DM_OK;
+  }
   dim3 grid(dm_cdiv(a.HW, a.pch), a.B), slabs(dm_cdiv(a.C, SL_C), a.B);
   hipLaunchKernelGGL(gn_stats_kernel, slabs, dim3(NT), 0, st, a);
   DM_CHECK_LAUNCH();
@@ -414,6 +693,11 @@ extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const v
   a.dss = dscale_shift; a.dpre = dpre_add; a.dup = dupstream_bias; a.ws = ws;
   fill(a, d);
   hipStream_t st = (hipStream_t)stream;
+  if (fused_ok(a, true)) {
+    hipLaunchKernelGGL(gn_bwd_fused_kernel<8>, dim3(dm_cdiv(a.C, 64), a.B), dim3(fused_threads(a)), 8 * fused_threads(a) * 16, st, a);
+    DM_CHECK_LAUNCH();
+    return DM_OK;
+  }
   dim3 grid(dm_cdiv(a.HW, a.pch), a.B), slabs(dm_cdiv(a.C, SL_C), a.B);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, slabs, dim3(NT), 0, st, a);
   DM_CHECK_LAUNCH();

@@ -31,7 +31,8 @@ typedef enum dm_status {
 const char* dm_last_error(void);
 int dm_abi_version(void);
 /* run-time switches: "conv_patch" (default 1): 3x3 stride-1 convs use the LDS-staged-patch kernel;
- * "wgrad_row3" (default 1): their weight gradients use the kernel that shares one staged input row among 3 taps */
+ * "wgrad_row3" (default 1): their weight gradients use the kernel that shares one staged input row among 3 taps;
+ * "gn_fused" (default 1): GroupNorm uses the single-pass (slab in registers) kernels where they apply */
 int dm_config_set(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -118,11 +118,26 @@ GN_CASES = [
     (2, 64, 0, 7, 7, False, False, False),      # plain GroupNorm (attention)
     (2, 128, 0, 5, 3, True, False, True),       # 'addition' embedding mixing
     (2, 512, 512, 2, 2, True, True, False),     # widest concat of the CIFAR model
+    (2, 128, 0, 32, 32, True, True, False),     # 1024 pixels: 16 pixels per thread in the single-pass forward
+    (3, 256, 0, 16, 16, True, True, False),     # 256 pixels: single-pass forward and backward
+    (2, 64, 0, 28, 28, True, False, False),     # 784 pixels: ragged pixel lanes
+    (2, 128, 0, 14, 14, False, False, True),    # 196 pixels, pre-add
+    (2, 72, 56, 8, 8, True, True, False),       # sources meet inside a 64-channel slab
 ]
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("B,C1,C2,H,W,act,ss,pre", GN_CASES)
-def test_groupnorm_act_fwd_bwd(B, C1, C2, H, W, act, ss, pre):
+def test_groupnorm_act_fwd_bwd(B, C1, C2, H, W, act, ss, pre, fused):
+    from dm_hip import lib
+    lib.dm_config_set(b"gn_fused", fused)   # single-pass kernels where they apply / always the two-sweep kernels
+    try:
+        _groupnorm_case(B, C1, C2, H, W, act, ss, pre)
+    finally:
+        lib.dm_config_set(b"gn_fused", 1)
+
+
+def _groupnorm_case(B, C1, C2, H, W, act, ss, pre):
     from dm_hip import ops
     rs = np.random.RandomState(B * 1000 + C1 + C2 + H)
     C, G = C1 + C2, 32
