@@ -12,9 +12,16 @@
 // One workgroup = one (tap, 128|64 output channels, 128|64 input channels) tile over one slice of the pixel
 // axis (split-K); partial tiles are transposed through LDS and added with 256-byte-contiguous fp32 atomics
 // into dw, which therefore ACCUMULATES (callers zero it or keep the running gradient in it).
+//
+// Float atomics execute at the memory side at about 1.3 TB/s chip-wide, a fifth of the plain-store rate, and one
+// round of workgroups adds a whole CU-full of accumulators (25 MB): with a caller-provided workspace the 3-tap
+// kernel therefore stores each partial tile as a slab (plain 16-byte stores, in accumulator-register order) and
+// a second, light kernel sums the slabs of a tile in slice order and adds the sum to dw - which also makes the
+// result independent of arrival order (bitwise reproducible).
 #include "dm_common.h"
 
 extern int g_dm_use_wgrad3;
+extern int g_dm_wgrad_slab_overhead;
 
 namespace {
 
@@ -25,6 +32,7 @@ struct WgradArgs {
   const void* x2;
   const void* dy;
   float* dw;
+  float* slabs;   // partial tiles [workgroup][SLAB_FLOATS] (3-tap kernel with a workspace), else null
   int C1, C2, Cin, Cout;
   int B, Hs, Ws, Hi, Wi, Ho, Wo, KH, KW, stride, pad, ups;
   int M, splitk, rows_per_split, n_co_tiles, n_ci_tiles, n_blocks;
@@ -322,7 +330,9 @@ __device__ __forceinline__ void read_tr(s16x4_t& v, unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
 }
 
-template <int NST>
+constexpr int SLAB_FLOATS = 3 * 128 * 64;   // one partial tile of the 3-tap kernel
+
+template <int NST, bool SLAB>
 __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
   constexpr int NT = 512, TCO = 128, TCI = 64;
   using TY = Tile<TCO, NT>;                       // dy tile: 64 pixels x 128 channels
@@ -503,9 +513,37 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
   }
   if (!lead && nsteps > 0) multiply();
 
-  // ---- epilogue: sum the wave groups and transpose through LDS (one buffer per tap), then fp32 atomics
   wait_vmcnt<0>();
   __syncthreads();
+  if constexpr (SLAB) {
+    // ---- epilogue with a workspace: sum the two wave groups through LDS in accumulator-register order (float4
+    // q = (tap, i, j) of thread t at [q][t]: conflict-free 16-byte accesses) and store the slab with plain stores
+    f32x4_t* ep4 = (f32x4_t*)smem;
+    const int t2 = tid & 255;
+    if (kg == 1) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) ep4[((t * MI + i) * NJ + j) * 256 + t2] = acc[t][i][j];
+    }
+    __syncthreads();
+    if (kg == 0) {
+      f32x4_t* slab = (f32x4_t*)a.slabs + (size_t)logical * (SLAB_FLOATS / 4);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int q = (t * MI + i) * NJ + j;
+            slab[q * 256 + t2] = ep4[q * 256 + t2] + acc[t][i][j];
+          }
+    }
+    return;
+  }
+  // ---- epilogue without: sum the wave groups and transpose through LDS (one buffer per tap), then fp32 atomics
   float* ep = (float*)smem;
   const int frow = lane & 15, fq = lane >> 4;
 #pragma unroll
@@ -534,6 +572,36 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
   }
 }
 
+// Sums the slabs of one tile over the pixel slices, in slice order, and adds the sum to dw. One workgroup per
+// (tile, float4 index q); thread t owns the float4 that thread t of the producing workgroups' first wave group held:
+// 4 consecutive output channels of one input channel.
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(WgradArgs a) {
+  const int per = 3 * a.n_co_tiles * a.n_ci_tiles;
+  const int inner = blockIdx.x / 24, q = blockIdx.x - inner * 24;
+  const int t2 = threadIdx.x;
+  const f32x4_t* src = (const f32x4_t*)a.slabs + (size_t)inner * (SLAB_FLOATS / 4) + q * 256 + t2;
+  const size_t stride = (size_t)per * (SLAB_FLOATS / 4);
+  f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  int ks = 0;
+  for (; ks + 4 <= a.splitk; ks += 4) {
+    const f32x4_t v0 = src[(size_t)ks * stride], v1 = src[(size_t)(ks + 1) * stride];
+    const f32x4_t v2 = src[(size_t)(ks + 2) * stride], v3 = src[(size_t)(ks + 3) * stride];
+    sum += v0; sum += v1; sum += v2; sum += v3;
+  }
+  for (; ks < a.splitk; ++ks) sum += src[(size_t)ks * stride];
+
+  const int tiles = a.n_co_tiles * a.n_ci_tiles;
+  const int kh = inner / tiles, rest = inner - kh * tiles;
+  const int tco = rest / a.n_ci_tiles, tci = rest - tco * a.n_ci_tiles;
+  const int t = q >> 3, i = (q >> 1) & 3, j = q & 1;
+  const int wave = t2 >> 6, lane = t2 & 63, wm = wave >> 1, wn = wave & 1;
+  const int co = tco * 128 + wm * 64 + i * 16 + (lane >> 4) * 4;
+  const int ci = tci * 64 + wn * 32 + j * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (co + r < a.Cout) a.dw[((size_t)(co + r) * 9 + kh * 3 + t) * a.Cin + ci] += sum[r];
+}
+
 void make_magic(unsigned d, unsigned& magic, unsigned& shift) {
   unsigned s = 0;
   while ((1ull << s) < d) ++s;
@@ -543,8 +611,52 @@ void make_magic(unsigned d, unsigned& magic, unsigned& shift) {
 
 }  // namespace
 
-extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,
-                               void* stream) {
+// The launch plan of a layer: kernel variant, tiles and pixel-axis split. `slabs`: partial tiles go to a workspace.
+struct WgradPlan {
+  bool row3, wide_co, wide_ci;
+  int n_co_tiles, n_ci_tiles, per, splitk, rows_per_split, n_blocks;
+  size_t ws_bytes;   // workspace the slab path needs (0: this layer has no slab path)
+};
+
+static WgradPlan make_plan(const dm_conv_desc* d, bool slabs) {
+  WgradPlan p;
+  const long M = (long)d->B * d->Ho * d->Wo;
+  const int Cin = d->C1 + d->C2;
+  p.row3 = g_dm_use_wgrad3 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Wo >= 8 &&
+           BKM % d->Wo == 0 && M % BKM == 0 && (BKM / d->Wo) * (d->Wo + 2) <= 128;
+  slabs = slabs && p.row3;
+  p.wide_co = d->Cout % 128 == 0;
+  p.wide_ci = d->C1 % 128 == 0 && d->C2 % 128 == 0;
+  const int tco = (p.wide_co || p.row3) ? 128 : 64, tci = (p.wide_ci && !p.row3) ? 128 : 64;
+  p.n_co_tiles = dm_cdiv(d->Cout, tco);
+  p.n_ci_tiles = Cin / tci;
+  p.per = (p.row3 ? 3 : d->KH * d->KW) * p.n_co_tiles * p.n_ci_tiles;
+  const int steps_total = dm_cdiv(M, BKM);
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  // Split the pixel axis to minimise rounds x (steps per workgroup + fixed cost): one workgroup per CU per round,
+  // the fixed cost (pipeline fill, partial tile out) counted as OVERHEAD steps - about 30 with partial-tile atomics
+  // (measured with cold caches), far less when the partial tile leaves as a slab.
+  const int OVERHEAD = slabs ? g_dm_wgrad_slab_overhead : 30;
+  const int max_split = steps_total / 8 > 0 ? (steps_total / 8 < 64 ? steps_total / 8 : 64) : 1;
+  int splitk = 1;
+  long best = -1;
+  for (int sk = 1; sk <= max_split; ++sk) {
+    const long cost = (long)dm_cdiv(p.per * sk, n_cu) * (dm_cdiv(steps_total, sk) + OVERHEAD);
+    if (best < 0 || cost < best) { best = cost; splitk = sk; }
+  }
+  p.rows_per_split = dm_cdiv(steps_total, splitk) * BKM;
+  p.splitk = dm_cdiv(M, p.rows_per_split);
+  p.n_blocks = p.splitk * p.per;
+  p.ws_bytes = slabs ? (size_t)p.n_blocks * SLAB_FLOATS * sizeof(float) : 0;
+  return p;
+}
+
+static int wgrad_impl(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, void* ws,
+                      size_t ws_bytes, void* stream) {
   DM_REQUIRE(d && x1 && dy && dw, DM_ERR_ARG, "dm_conv2d_wgrad: null argument");
   DM_REQUIRE(d->C1 > 0 && d->C1 % 64 == 0 && d->C2 >= 0 && d->C2 % 64 == 0, DM_ERR_SHAPE,
              "dm_conv2d_wgrad: input channels (%d, %d) must be multiples of 64", d->C1, d->C2);
@@ -577,42 +689,38 @@ extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void
   a.dh_step = (BKM % (d->Ho * d->Wo)) / d->Wo;
   a.dw_step = (BKM % (d->Ho * d->Wo)) % d->Wo;
 
-  const bool row3 = g_dm_use_wgrad3 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Wo >= 8 &&
-                    BKM % d->Wo == 0 && M % BKM == 0 && (BKM / d->Wo) * (d->Wo + 2) <= 128;
-  const bool wide_co = d->Cout % 128 == 0;
-  const bool wide_ci = d->C1 % 128 == 0 && d->C2 % 128 == 0;
-  const int tco = (wide_co || row3) ? 128 : 64, tci = (wide_ci && !row3) ? 128 : 64;
-  a.n_co_tiles = dm_cdiv(d->Cout, tco);
-  a.n_ci_tiles = a.Cin / tci;
-  const int per = (row3 ? 3 : d->KH * d->KW) * a.n_co_tiles * a.n_ci_tiles;
-  // One workgroup per CU: split the pixel axis so that one round of workgroups covers the chip (every further
-  // split adds a full partial tile of fp32 atomics per workgroup), but keep >= 8 steps per workgroup.
-  const int steps_total = dm_cdiv(M, BKM);
-  static const int n_cu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
-  // Split the pixel axis to minimise rounds x (steps per workgroup + fixed cost): one workgroup per CU per round,
-  // the fixed cost (pipeline fill, partial-tile atomics) counted as OVERHEAD steps.
-  constexpr int OVERHEAD = 30;   // measured with cold caches: pipeline fill + partial-tile atomics cost about 30 steps
-  const int max_split = steps_total / 8 > 0 ? (steps_total / 8 < 64 ? steps_total / 8 : 64) : 1;
-  int splitk = 1;
-  long best = -1;
-  for (int sk = 1; sk <= max_split; ++sk) {
-    const long cost = (long)dm_cdiv(per * sk, n_cu) * (dm_cdiv(steps_total, sk) + OVERHEAD);
-    if (best < 0 || cost < best) { best = cost; splitk = sk; }
-  }
-  a.rows_per_split = dm_cdiv(steps_total, splitk) * BKM;
-  a.splitk = dm_cdiv(M, a.rows_per_split);
-  a.n_blocks = a.splitk * per;
+  const WgradPlan p = make_plan(d, ws != nullptr);
+  DM_REQUIRE(ws_bytes >= p.ws_bytes, DM_ERR_ARG, "dm_conv2d_wgrad_ws: workspace of %zu bytes, %zu needed", ws_bytes, p.ws_bytes);
+  DM_REQUIRE(((uintptr_t)ws) % 16 == 0, DM_ERR_ARG, "dm_conv2d_wgrad_ws: workspace must be 16-byte aligned");
+  const bool row3 = p.row3, wide_co = p.wide_co, wide_ci = p.wide_ci;
+  a.n_co_tiles = p.n_co_tiles; a.n_ci_tiles = p.n_ci_tiles;
+  a.rows_per_split = p.rows_per_split; a.splitk = p.splitk; a.n_blocks = p.n_blocks;
+  a.slabs = p.ws_bytes ? (float*)ws : nullptr;
   dim3 grid((a.n_blocks + 7) / 8 * 8), block(512);
   hipStream_t st = (hipStream_t)stream;
-  if (row3) hipLaunchKernelGGL((conv_wgrad3_kernel<4>), grid, block, 0, st, a);
+  if (row3 && a.slabs) {
+    hipLaunchKernelGGL((conv_wgrad3_kernel<4, true>), grid, block, 0, st, a);
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(p.per * 24), dim3(256), 0, st, a);
+  } else if (row3) hipLaunchKernelGGL((conv_wgrad3_kernel<4, false>), grid, block, 0, st, a);
   else if (wide_co && wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2>), grid, block, 0, st, a);
   else if (wide_co) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 4, 2>), grid, block, 0, st, a);
   else if (wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, 2>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 4, 2>), grid, block, 0, st, a);
   DM_CHECK_LAUNCH();
   return DM_OK;
+}
+
+extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,
+                               void* stream) {
+  return wgrad_impl(d, x1, x2, dy, dw, nullptr, 0, stream);
+}
+
+extern "C" size_t dm_conv2d_wgrad_ws_bytes(const dm_conv_desc* d) {
+  return d ? make_plan(d, true).ws_bytes : 0;
+}
+
+extern "C" int dm_conv2d_wgrad_ws(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(ws || ws_bytes == 0, DM_ERR_ARG, "dm_conv2d_wgrad_ws: null workspace with a size");
+  return wgrad_impl(d, x1, x2, dy, dw, ws, ws_bytes, stream);
 }

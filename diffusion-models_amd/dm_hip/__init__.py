@@ -46,6 +46,8 @@ _SIGNATURES = {
     "dm_config_set": (c_int, [ctypes.c_char_p, c_int]),
     "dm_conv2d_igemm": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "dm_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
+    "dm_conv2d_wgrad_ws_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "dm_conv2d_wgrad_ws": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, ctypes.c_size_t, P]),
     "dm_pack_conv_weight": (c_int, [P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, P, P]),
     "dm_transpose_conv_weights": (c_int, [P, P, P, c_int, c_int, P]),
     "dm_colsum_bf16": (c_int, [P, P, c_long, c_int, P]),

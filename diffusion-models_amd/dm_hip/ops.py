@@ -210,13 +210,13 @@ class _ConvFn(Function):
         want_db = has_bias and ctx.needs_input_grad[3]
         bsink = _grad_sink(bparam) if want_db else None
         on_side = SIDE_WGRAD and (wsink is not None or not ctx.needs_input_grad[2]) and (bsink is not None or not want_db)
-        st_w = st
+        st_w, stream_w = st, torch.cuda.current_stream()
         if on_side:
             global _SIDE_NEXT
             side = side_stream(dy.device, _SIDE_NEXT % SIDE_WGRAD)
             _SIDE_NEXT += 1
             side.wait_stream(torch.cuda.current_stream())  # dy (and the saved inputs) are complete
-            st_w = side.cuda_stream
+            st_w, stream_w = side.cuda_stream, side
             for t in (dy, x1, x2):
                 if t is not None:
                     t.record_stream(side)
@@ -237,7 +237,15 @@ class _ConvFn(Function):
         if ctx.needs_input_grad[2]:
             dwf = wsink if wsink is not None else torch.zeros((Cout, KH, KW, Cin), dtype=torch.float32, device=dy.device)
             d = _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, 0, Ho, Wo)
-            check(lib.dm_conv2d_wgrad(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(), st_w))
+            # split-K partial tiles go through a scratch workspace where the layer has that path (no float atomics,
+            # order-independent sums); allocated on the stream that runs the kernel
+            ws_bytes = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(d))
+            ws = None
+            if ws_bytes:
+                with torch.cuda.stream(stream_w):
+                    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+            check(lib.dm_conv2d_wgrad_ws(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(),
+                                         _p(ws), ws_bytes, st_w))
             if wsink is not None:
                 _grad_done(wparam)
             else:

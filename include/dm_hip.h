@@ -66,6 +66,17 @@ int dm_conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const
 /* dw[n][tap][c] += sum_m dy[m][n] * X(m,tap)[c]; dw fp32 [Cout][KH*KW][C1+C2], ACCUMULATES (atomics) */
 int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, void* stream);
 
+/* The same with a caller-provided scratch workspace (16-byte aligned, at least dm_conv2d_wgrad_ws_bytes(d) bytes,
+ * contents irrelevant on entry and on return; null / 0 selects the call above). Where the layer has a slab path
+ * (3x3, stride 1, pad 1, output width 8..64 dividing 64), the split-K partial tiles go to the workspace with plain
+ * stores and a second kernel adds their sum to dw: no float atomics, and a result that does not depend on the
+ * order in which workgroups finish. dm_conv2d_wgrad_ws_bytes returns 0 for layers without that path.
+ * Same operator as above: the weight gradient autograd computes for nn.Conv2d of modeling/blocks.py:26,28,110
+ * inside loss.backward() (train.py:440). */
+size_t dm_conv2d_wgrad_ws_bytes(const dm_conv_desc* d);
+int dm_conv2d_wgrad_ws(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, void* ws,
+                       size_t ws_bytes, void* stream);
+
 /* fp32 parameter [Cout][Cin][KH][KW] with arbitrary element strides -> bf16 [Cout][T][Cin] (w_fwd) and
  * bf16 [Cin][T][Cout] (w_dgrad); either output may be null */
 int dm_pack_conv_weight(const float* w, long s_co, long s_ci, long s_kh, long s_kw, int Cout, int Cin, int KH,

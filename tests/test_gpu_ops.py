@@ -109,6 +109,49 @@ def _conv2d_case(B, C1, C2, Cout, H, W, k, stride, ups):
     assert rel_err(resd.grad.float(), resr.grad) < 1e-6
 
 
+@pytest.mark.parametrize("B,C1,C2,Cout,H,W,ups", [
+    (64, 128, 0, 128, 32, 32, 0),     # many pixel slices per tile
+    (32, 64, 64, 192, 16, 16, 0),     # two sources, Cout not a multiple of the 128-channel tile
+    (16, 128, 0, 64, 8, 8, 1),        # fused upsample, half-empty output-channel tile
+    (2, 64, 0, 64, 8, 8, 0),          # a single slice
+])
+def test_conv2d_wgrad_workspace(B, C1, C2, Cout, H, W, ups):
+    """The slab path of the weight gradient (partial tiles to a workspace, summed by a second kernel) against the
+    atomic path on the same inputs; it accumulates into dw like the atomic path, leaves dw alone outside the
+    tensor, and gives bit-identical results from run to run (sums in slice order)."""
+    import ctypes
+    from dm_hip import ConvDesc, check, lib
+    d_ = dev()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cout)
+    bf = torch.bfloat16
+    Ho, Wo = H << ups, W << ups
+    Cin = C1 + C2
+    x1 = torch.randn(B, H, W, C1, generator=g).to(bf).to(d_)
+    x2 = torch.randn(B, H, W, C2, generator=g).to(bf).to(d_) if C2 else None
+    dy = torch.randn(B, Ho, Wo, Cout, generator=g).to(bf).to(d_)
+    desc = ConvDesc(B, H, W, C1, C2, Cout, 3, 3, 1, 1, ups, 0, Ho, Wo)
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    nbytes = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(desc))
+    assert nbytes > 0 and nbytes % (3 * 128 * 64 * 4) == 0
+    base = torch.randn(Cout * 9 * Cin + 64, generator=g).to(d_)       # dw accumulates; 64 guard floats behind it
+    ref = base.clone()
+    check(lib.dm_conv2d_wgrad(ctypes.byref(desc), p(x1), p(x2), p(dy), ref.data_ptr(), st))
+    outs = []
+    for fill in (0.0, float("nan")):                                   # the workspace's contents do not matter
+        ws = torch.full((nbytes // 4,), fill, device=d_)
+        out = base.clone()
+        check(lib.dm_conv2d_wgrad_ws(ctypes.byref(desc), p(x1), p(x2), p(dy), out.data_ptr(), ws.data_ptr(), nbytes, st))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0][-64:], base[-64:])
+    assert rel_err(outs[0][:-64] - base[:-64], ref[:-64] - base[:-64]) < 1e-5   # fp32 sums in a different order
+    # too small a workspace is an error, not a silent fallback
+    small = torch.empty(16, device=d_)
+    assert lib.dm_conv2d_wgrad_ws(ctypes.byref(desc), p(x1), p(x2), p(dy), out.data_ptr(), small.data_ptr(), 64, st) != 0
+
+
 GN_CASES = [
     # B, C1, C2, H, W, act, ss, pre
     (2, 64, 0, 8, 8, True, False, False),

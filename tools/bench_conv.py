@@ -71,6 +71,8 @@ def main():
     only = sys.argv[1] if len(sys.argv) > 1 else None
     which = sys.argv[2] if len(sys.argv) > 2 else "fdw"   # f(orward) d(ata gradient) w(eight gradient)
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
+    if os.environ.get("DM_SLAB_OVERHEAD"):
+        check(lib.dm_config_set(b"wgrad_slab_overhead", int(os.environ["DM_SLAB_OVERHEAD"])))
     for name, B, H, W, C1, C2, Cout, k, stride, ups in SHAPES:
         if only and only not in name:
             continue
@@ -101,7 +103,9 @@ def main():
         if "d" in which:
             t_d = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(dt), p(dy), None, p(wt), None, None, p(dx), st)), warm=[dy])
         if "w" in which:
-            t_w = timeit(lambda: check(lib.dm_conv2d_wgrad(ctypes.byref(d), p(x1), p(x2), p(dy), p(dw), st)), warm=[dy])
+            wsb = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(d)) if os.environ.get("DM_BENCH_WS", "1") == "1" else 0
+            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+            t_w = timeit(lambda: check(lib.dm_conv2d_wgrad_ws(ctypes.byref(d), p(x1), p(x2), p(dy), p(dw), p(ws) if wsb else None, wsb, st)), warm=[dy])
         for key, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
             tot[key][0] += flops
             tot[key][1] += t
