@@ -100,6 +100,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  // n / d for 0 <= n < 2^20 as a float multiply (exact: (n + 0.5) / d is at least 0.5 / d away from an integer, far
+  // more than the rounding error of the product); the index set-up below would otherwise spend thousands of cycles
+  // in two dozen integer divisions per thread before the first load is issued
+  auto fdiv = [](int n, float inv) { return (int)(((float)n + 0.5f) * inv); };
+  const float inv_pw = 1.0f / (float)a.PW, inv_h2 = 1.0f / (float)(a.H + 2), inv_w = 1.0f / (float)a.W,
+              inv_h = 1.0f / (float)a.H;
 
   __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x1), 0, a.x1_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x2 ? a.x2 : a.x1), 0,
@@ -113,12 +119,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int pp = spix + 64 * i;
-    const int pr = pp / a.PW, pc = pp - pr * a.PW;
+    const int pr = fdiv(pp, inv_pw), pc = pp - pr * a.PW;
     int k, local, ystart;
     if (pr < nrow0 + 2) { k = 0; local = pr; ystart = y0; }
     else {
       const int q = pr - (nrow0 + 2);
-      k = 1 + q / (a.H + 2);
+      k = 1 + fdiv(q, inv_h2);
       local = q - (k - 1) * (a.H + 2);
       ystart = 0;
     }
@@ -160,9 +166,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int lp = wm * 64 + i * 16 + frow;
-    const int ry = lp / a.W, x = lp - ry * a.W;
+    const int ry = fdiv(lp, inv_w), x = lp - ry * a.W;
     const int r = R0 + ry;
-    if (ry < a.TR && r < a.B * a.H) pA[i] = (ry + 2 * (r / a.H - b0)) * a.PW + x;
+    if (ry < a.TR && r < a.B * a.H) pA[i] = (ry + 2 * (fdiv(r, inv_h) - b0)) * a.PW + x;
     else pA[i] = 0;  // rows outside the tile compute garbage that is never stored
   }
   int b_off[NJ][2];
@@ -348,6 +354,7 @@ int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, con
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return DM_ERR_UNSUPPORTED;
   const int H = d->Ho, W = d->Wo;
   if (W > BM || d->Cout % 8) return DM_ERR_UNSUPPORTED;
+  if ((long)d->B * H >= (1 << 20) - BM) return DM_ERR_UNSUPPORTED;   // the kernel's float-multiply divisions are exact below 2^20
   const int Cin = d->C1 + d->C2;
   if (Cin % BK || d->C1 % BK) return DM_ERR_UNSUPPORTED;
   // narrow outputs on small images: 64-column tiles keep every CU busy
