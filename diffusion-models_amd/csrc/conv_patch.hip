@@ -114,12 +114,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
 
   // ---- patch staging: this thread's NP pieces = fixed 16-byte slot (tid & 7) of patch pixels (tid >> 3) + 64 * i
   const int spix = tid >> 3;
-  const int chunkA = (tid & 7) ^ (spix & 7);   // (pixel & 7) is the same for all i
+  // 16-byte slot s of patch pixel (row, column pc) holds channel piece s ^ (pc & 7). Keyed on the COLUMN, not the
+  // pixel index: the 16 rows of an MFMA tile are 16 consecutive pixels of one image row or, on 8-wide images, 8 + 8
+  // pixels of two image rows with equal columns, and either way the 8 lanes that one LDS cycle serves per 32-channel
+  // half see 8 different columns mod 8 (a pixel-index key collides on 8-wide images: the row pitch is 10).
+  int akey[NP];
   int gsrc[NP];                                // source pixel index, -1: zero
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int pp = spix + 64 * i;
     const int pr = fdiv(pp, inv_pw), pc = pp - pr * a.PW;
+    akey[i] = (tid & 7) ^ (pc & 7);
     int k, local, ystart;
     if (pr < nrow0 + 2) { k = 0; local = pr; ystart = y0; }
     else {
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
     const bool second = cc >= a.C1;
     if (cc < a.Cin && gsrc[i] >= 0) {
       const int csrc = second ? a.C2 : a.C1;
-      off = (unsigned)(gsrc[i] * csrc * 2 + (second ? cc - a.C1 : cc) * 2 + chunkA * 16);
+      off = (unsigned)(gsrc[i] * csrc * 2 + (second ? cc - a.C1 : cc) * 2 + akey[i] * 16);
     }
     char* dst = smem + (buf ? L::A1 : L::A0) + (wave * 64 + NTHREADS * i) * 16;
     if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, DM_LDS(dst), 16, off, 0, 0, 0);
@@ -163,6 +168,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
   // ---- fragment geometry
   const int frow = lane & 15, fq = lane >> 4;
   int pA[MI];       // patch pixel of this lane's row of M-tile i at tap offset 0
+  int xA[MI];       // its column in the tile (patch column at tap offset 0)
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int lp = wm * 64 + i * 16 + frow;
@@ -170,6 +176,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
     const int r = R0 + ry;
     if (ry < a.TR && r < a.B * a.H) pA[i] = (ry + 2 * (fdiv(r, inv_h) - b0)) * a.PW + x;
     else pA[i] = 0;  // rows outside the tile compute garbage that is never stored
+    xA[i] = x;
   }
   int b_off[NJ][2];
 #pragma unroll
@@ -242,6 +249,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
       }
       const int kh = tap / 3, kw = tap - kh * 3;
       const int toff = a.transposed ? ((2 - kh) * pw + (2 - kw)) : (kh * pw + kw);
+      const int coff = a.transposed ? 2 - kw : kw;   // column part of the tap offset
       if constexpr (SHIFT) {
         const unsigned bbase = lds_base + L::B0 + (tap % 3) * L::B_BYTES;
 #pragma unroll
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
             const int p = pA[i] + toff;
-            lds_read128(af[kk][i], abase + (p << 7) + ((((kk * 4 + fq) ^ p) & 7) << 4));
+            lds_read128(af[kk][i], abase + (p << 7) + ((((kk * 4 + fq) ^ (xA[i] + coff)) & 7) << 4));
           }
 #pragma unroll
           for (int j = 0; j < NJ; ++j) lds_read128(bfr[kk][j], bbase + b_off[j][kk]);
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
             const int p = pA[i] + toff;
-            a2[i] = *(const bf16x8_t*)(abuf + (p << 7) + ((((kk * 4 + fq) ^ p) & 7) << 4));
+            a2[i] = *(const bf16x8_t*)(abuf + (p << 7) + ((((kk * 4 + fq) ^ (xA[i] + coff)) & 7) << 4));
           }
 #pragma unroll
           for (int j = 0; j < NJ; ++j) b2[j] = *(const bf16x8_t*)(bbuf + b_off[j][kk]);

@@ -372,6 +372,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
   const int nsteps = (m_end - m_begin + BKM - 1) / BKM;
   const int PW = a.Wo + 2, RS = BKM / a.Wo, npatch = RS * PW;
 
+  // Swizzle of the 16-byte pieces of patch pixel pp = (prow, pcol). One transposing read serves 4 + 4 pixels that are
+  // 8 apart in the 64-pixel step: neighbours in one patch row on images >= 16 wide (the pixel-index key of the plain
+  // tiles separates them), but the SAME columns of two consecutive patch rows on 8-wide images, where the row pitch
+  // of 10 makes that key collide - there the key is (column bit 1, row bit 0).
+  const bool narrow = a.Wo == 8;
+  auto patch_swz = [&](int pp, int prow, int pcol) {
+    return narrow ? ((((pcol >> 1) & 1) | ((prow & 1) << 1)) << 1) : swz<8>(pp);
+  };
   // dy staging (as in the single-tap kernel)
   const int yrow = tid / TY::PPR, yslot = tid % TY::PPR;
   const int ypiece = yslot ^ swz<TY::PPR>(yrow);
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
     crow[i] = gr - b * a.Ho;
     const int iw = pcol - 1;
     xcol[i] = (pp < npatch && iw >= 0 && iw < a.Wi) ? (iw >> a.ups) : -1;
-    xconst[i] = (cioff + ((slot ^ swz<8>(pp)) << 3)) * 2;
+    xconst[i] = (cioff + ((slot ^ patch_swz(pp, prow, pcol)) << 3)) * 2;
   }
   const int db_hs = (RS / a.Ho) * a.Hs, dh = RS % a.Ho;
   const int csrc2 = csrc * 2;
@@ -451,7 +459,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int piece = ((wn * 32 + j * 16) >> 3) + (p >> 1);
-          b_off[t][h][j] = TY::BYTES + pp * 128 + ((piece ^ swz<8>(pp)) << 4) + (p & 1) * 8;
+          b_off[t][h][j] = TY::BYTES + pp * 128 + ((piece ^ patch_swz(pp, prow, pcol + t)) << 4) + (p & 1) * 8;
         }
       }
     }
