@@ -580,31 +580,40 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
   }
 }
 
-// Sums the slabs of one tile over the pixel slices, in slice order, and adds the sum to dw. One workgroup per
-// (tile, float4 index q); thread t owns the float4 that thread t of the producing workgroups' first wave group held:
-// 4 consecutive output channels of one input channel.
+// Sums the slabs of one tile over the pixel slices and adds the sum to dw, in a fixed order: one workgroup per
+// (tile, 64 consecutive float4s of the slab); wave g sums slices g, g + 4, g + 8, ... (a slice is 1 KiB per wave
+// load), the four partial sums are added in wave order. Lane t of the 64 owns the float4 that thread (q, t2) of the
+// producing workgroups' first wave group held: 4 consecutive output channels of one input channel.
 __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(WgradArgs a) {
+  __shared__ f32x4_t red[3][64];
+  constexpr int F4 = SLAB_FLOATS / 4, CH = F4 / 64;   // float4s per slab, 64-float4 chunks per slab
   const int per = 3 * a.n_co_tiles * a.n_ci_tiles;
-  const int inner = blockIdx.x / 24, q = blockIdx.x - inner * 24;
-  const int t2 = threadIdx.x;
-  const f32x4_t* src = (const f32x4_t*)a.slabs + (size_t)inner * (SLAB_FLOATS / 4) + q * 256 + t2;
-  const size_t stride = (size_t)per * (SLAB_FLOATS / 4);
+  const int inner = blockIdx.x / CH, chunk = blockIdx.x - inner * CH;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = chunk * 64 + lane;                     // float4 index in the slab = q * 256 + t2
+  const f32x4_t* src = (const f32x4_t*)a.slabs + (size_t)inner * F4 + e;
+  const size_t stride = (size_t)per * F4;
   f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  int ks = 0;
-  for (; ks + 4 <= a.splitk; ks += 4) {
-    const f32x4_t v0 = src[(size_t)ks * stride], v1 = src[(size_t)(ks + 1) * stride];
-    const f32x4_t v2 = src[(size_t)(ks + 2) * stride], v3 = src[(size_t)(ks + 3) * stride];
+  int ks = grp;
+  for (; ks + 12 < a.splitk; ks += 16) {
+    const f32x4_t v0 = src[(size_t)ks * stride], v1 = src[(size_t)(ks + 4) * stride];
+    const f32x4_t v2 = src[(size_t)(ks + 8) * stride], v3 = src[(size_t)(ks + 12) * stride];
     sum += v0; sum += v1; sum += v2; sum += v3;
   }
-  for (; ks < a.splitk; ++ks) sum += src[(size_t)ks * stride];
+  for (; ks < a.splitk; ks += 4) sum += src[(size_t)ks * stride];
+  if (grp) red[grp - 1][lane] = sum;
+  __syncthreads();
+  if (grp) return;
+  sum += red[0][lane]; sum += red[1][lane]; sum += red[2][lane];
 
+  const int q = e >> 8, t2 = e & 255;
   const int tiles = a.n_co_tiles * a.n_ci_tiles;
   const int kh = inner / tiles, rest = inner - kh * tiles;
   const int tco = rest / a.n_ci_tiles, tci = rest - tco * a.n_ci_tiles;
   const int t = q >> 3, i = (q >> 1) & 3, j = q & 1;
-  const int wave = t2 >> 6, lane = t2 & 63, wm = wave >> 1, wn = wave & 1;
-  const int co = tco * 128 + wm * 64 + i * 16 + (lane >> 4) * 4;
-  const int ci = tci * 64 + wn * 32 + j * 16 + (lane & 15);
+  const int wave = t2 >> 6, l2 = t2 & 63, wm = wave >> 1, wn = wave & 1;
+  const int co = tco * 128 + wm * 64 + i * 16 + (l2 >> 4) * 4;
+  const int ci = tci * 64 + wn * 32 + j * 16 + (l2 & 15);
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (co + r < a.Cout) a.dw[((size_t)(co + r) * 9 + kh * 3 + t) * a.Cin + ci] += sum[r];
@@ -708,7 +717,7 @@ static int wgrad_impl(const dm_conv_desc* d, const void* x1, const void* x2, con
   hipStream_t st = (hipStream_t)stream;
   if (row3 && a.slabs) {
     hipLaunchKernelGGL((conv_wgrad3_kernel<4, true>), grid, block, 0, st, a);
-    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(p.per * 24), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(p.per * (SLAB_FLOATS / 256)), dim3(256), 0, st, a);
   } else if (row3) hipLaunchKernelGGL((conv_wgrad3_kernel<4, false>), grid, block, 0, st, a);
   else if (wide_co && wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2>), grid, block, 0, st, a);
   else if (wide_co) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 4, 2>), grid, block, 0, st, a);

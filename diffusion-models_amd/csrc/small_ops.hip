@@ -185,9 +185,11 @@ constexpr int GT_M = 128, GT_K = 128, GT_N = 64;   // tile of rows (batch), inpu
 constexpr int GT_PITCH = GT_M + 4;
 constexpr int GT_XN = 256;   // output features one workgroup of the input-gradient kernel covers (4 slices)
 
-// dx[m][k] += f'(x[m][k]) * sum_{n in slice} dy_p[m][n] w_p[n][k]   (atomics: one partial per slice; dx zeroed by the caller)
-__global__ __launch_bounds__(NT) void linear_group_bwd_x_kernel(const float* __restrict__ x, const LinearGroup g,
-                                                                float* __restrict__ dx, int M, int K, int act_in) {
+// Input gradient in two steps without atomics (several dozen workgroups adding into one 256 KB dx through float
+// atomics ran at a tenth of the atomic rate: every adder hits the same rows):
+//   part[s][m][k] = sum_{n in slice group s} dy_p[m][n] w_p[n][k]      (plain stores into the workspace)
+//   dx[m][k]      = f'(x[m][k]) * sum_s part[s][m][k]                  (fixed order)
+__global__ __launch_bounds__(NT) void linear_group_bwd_x_kernel(const LinearGroup g, float* __restrict__ part, int M, int K) {
   __shared__ __attribute__((aligned(16))) float sdy[GT_N * GT_PITCH];  // [n][m], transposed
   __shared__ __attribute__((aligned(16))) float sw[GT_N * GT_K];       // [n][k]
   const LinearGroupItem it = g.it[find_item(g, blockIdx.x)];
@@ -199,7 +201,6 @@ __global__ __launch_bounds__(NT) void linear_group_bwd_x_kernel(const float* __r
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
-  // a workgroup sums GT_XN / GT_N slices itself before its atomics: fewer adders per dx element
   for (int n0 = nb; n0 < min(N, nb + GT_XN); n0 += GT_N) {
     __syncthreads();
     for (int i = threadIdx.x; i < GT_M * GT_N; i += NT) {
@@ -223,28 +224,39 @@ __global__ __launch_bounds__(NT) void linear_group_bwd_x_kernel(const float* __r
         for (int j = 0; j < 8; ++j) acc[i][j] += dv[i] * wv[j];
     }
   }
-  // through LDS, 64 rows at a time, so that a wave's atomics cover 256 contiguous bytes of one dx row
-  float* ep = sdy;  // [64][GT_PITCH]
+  // the 16 threads of a row group cover 512 contiguous bytes of each row
+  float* out = part + (size_t)blockIdx.x * M * K;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();
-    if ((ty >> 3) == half) {
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + ty * 8 + i, k = k0 + tx * 8;
+    if (m < M) {
+      if (k + 8 <= K && K % 4 == 0) {
+        *(f32x4_t*)(out + (size_t)m * K + k) = f32x4_t{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+        *(f32x4_t*)(out + (size_t)m * K + k + 4) = f32x4_t{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+      } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ep[((ty & 7) * 8 + i) * GT_PITCH + tx * 8 + j] = acc[i][j];
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 64 * GT_K; idx += NT) {
-      const int row = idx / GT_K, col = idx - row * GT_K;
-      const int m = m0 + half * 64 + row, k = k0 + col;
-      if (m < M && k < K) {
-        float v = ep[row * GT_PITCH + col];
-        if (act_in) v *= dm_silu_grad(x[(size_t)m * K + k]);
-        atomicAdd(dx + (size_t)m * K + k, v);
+        for (int j = 0; j < 8; ++j)
+          if (k + j < K) out[(size_t)m * K + k + j] = acc[i][j];
       }
     }
   }
+}
+
+// dx = f'(x) * sum over the slice groups, in group order: a workgroup owns 64 elements, wave g sums groups g, g+4, ...
+__global__ __launch_bounds__(NT) void linear_group_bwd_x_sum_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                                    float* __restrict__ dx, int total, int nparts, int act_in) {
+  __shared__ float red[3][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (e < total)
+    for (int q = grp; q < nparts; q += 4) s += part[(size_t)q * total + e];
+  if (grp) red[grp - 1][lane] = s;
+  __syncthreads();
+  if (grp || e >= total) return;
+  s = ((s + red[0][lane]) + red[1][lane]) + red[2][lane];
+  if (act_in) s *= dm_silu_grad(x[e]);
+  dx[e] = s;
 }
 
 // dw_p[n][k] += sum_m dy_p[m][n] f(x[m][k]); db_p[n] += sum_m dy_p[m][n]; one workgroup owns a 64 x 128 tile of dw_p
@@ -536,9 +548,18 @@ extern "C" int dm_linear_group_fwd(const float* x, const dm_linear_item* items, 
   return DM_OK;
 }
 
-extern "C" int dm_linear_group_bwd(const float* x, const dm_linear_item* items, int P, float* dx, int M, int K, int act_in,
-                                   void* stream) {
+extern "C" long dm_linear_group_bwd_ws_floats(const dm_linear_item* items, int P, int M, int K) {
+  if (!items || P <= 0 || M <= 0 || K <= 0) return 0;
+  long t = 0;
+  for (int p = 0; p < P; ++p) t += dm_cdiv(items[p].N, GT_XN);
+  return t * M * K;
+}
+
+extern "C" int dm_linear_group_bwd(const float* x, const dm_linear_item* items, int P, float* dx, float* ws, int M, int K,
+                                   int act_in, void* stream) {
   DM_REQUIRE(x && M > 0 && K > 0, DM_ERR_ARG, "dm_linear_group_bwd: bad argument");
+  DM_REQUIRE(!dx || (ws && (uintptr_t)ws % 16 == 0), DM_ERR_ARG, "dm_linear_group_bwd: dx needs a 16-byte aligned workspace");
+  static_assert(NT == 256, "the sum kernel assumes four waves");
   LinearGroup g;
   int tiles = 0;
   int rc = fill_group(g, items, P, GT_N, &tiles);
@@ -550,12 +571,9 @@ extern "C" int dm_linear_group_bwd(const float* x, const dm_linear_item* items, 
   for (int p = 0; p < P; ++p) DM_REQUIRE(items[p].dy, DM_ERR_ARG, "dm_linear_group_bwd: layer %d has no output gradient", p);
   hipStream_t st = (hipStream_t)stream;
   if (dx) {
-    if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * K, st) != hipSuccess) {
-      dm_set_error("dm_linear_group_bwd: memset failed");
-      return DM_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL(linear_group_bwd_x_kernel, dim3(xtiles, dm_cdiv(M, GT_M), dm_cdiv(K, GT_K)), dim3(NT), 0, st, x, gx, dx,
-                       M, K, act_in);
+    hipLaunchKernelGGL(linear_group_bwd_x_kernel, dim3(xtiles, dm_cdiv(M, GT_M), dm_cdiv(K, GT_K)), dim3(NT), 0, st, gx, ws, M, K);
+    DM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(linear_group_bwd_x_sum_kernel, dim3(dm_cdiv((long)M * K, 64)), dim3(NT), 0, st, x, ws, dx, M * K, xtiles, act_in);
     DM_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(linear_group_bwd_w_kernel, dim3(tiles, dm_cdiv(K, GT_K)), dim3(NT), 0, st, x, g, M, K, act_in);

@@ -65,7 +65,8 @@ _SIGNATURES = {
     "dm_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dm_linear_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dm_linear_group_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
-    "dm_linear_group_bwd": (c_int, [P, P, c_int, P, c_int, c_int, c_int, P]),
+    "dm_linear_group_bwd_ws_floats": (c_long, [P, c_int, c_int, c_int]),
+    "dm_linear_group_bwd": (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, P]),
     "dm_class_embed_add": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "dm_class_embed_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "dm_upsample2x_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -505,7 +505,10 @@ class _LinearGroupFn(Function):
                 grads[2 * i + 1] = db
             else:
                 sinks.append(bs[i])
-        check(lib.dm_linear_group_bwd(x32.data_ptr(), items, P, _p(dx), M, K, act_in, _stream()))
+        scratch = None
+        if dx is not None:
+            scratch = torch.empty(lib.dm_linear_group_bwd_ws_floats(items, P, M, K), dtype=torch.float32, device=dev)
+        check(lib.dm_linear_group_bwd(x32.data_ptr(), items, P, _p(dx), _p(scratch), M, K, act_in, _stream()))
         for prm in sinks:
             _grad_done(prm)
         return (dx, None) + tuple(grads)

@@ -189,8 +189,11 @@ typedef struct dm_linear_item {
   int N;
 } dm_linear_item;
 int dm_linear_group_fwd(const float* x, const dm_linear_item* items, int P, int M, int K, int act_in, void* stream);
-int dm_linear_group_bwd(const float* x, const dm_linear_item* items, int P, float* dx, int M, int K, int act_in,
-                        void* stream);
+/* ws: scratch of dm_linear_group_bwd_ws_floats(items, P, M, K) floats (16-byte aligned; needed when dx is given): the
+ * input gradient is summed from per-slice partial tiles in a fixed order, without float atomics */
+long dm_linear_group_bwd_ws_floats(const dm_linear_item* items, int P, int M, int K);
+int dm_linear_group_bwd(const float* x, const dm_linear_item* items, int P, float* dx, float* ws, int M, int K,
+                        int act_in, void* stream);
 /* emb[b][:] += table[idx(b)][:], idx(b) = (cls == null || mask[b] != 0) ? uncond_idx : cls[b] */
 int dm_class_embed_add(float* emb, const float* table, const int64_t* cls, const float* mask, int uncond_idx, int B,
                        int E, void* stream);
