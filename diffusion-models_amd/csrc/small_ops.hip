@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NT) void linear_group_fwd_kernel(const float* __res
 // walks 64-wide slices of all layers' N axes: item.tile0 = first slice of a layer).
 constexpr int GT_M = 128, GT_K = 128, GT_N = 64;   // tile of rows (batch), input features, slice of output features
 constexpr int GT_PITCH = GT_M + 4;
-constexpr int GT_XN = 256;   // output features one workgroup of the input-gradient kernel covers (4 slices)
+constexpr int GT_XN = 64;    // output features one workgroup of the input-gradient kernel covers (the layers are few and narrow: more workgroups matter more than fewer partial tiles)
 
 // Input gradient in two steps without atomics (several dozen workgroups adding into one 256 KB dx through float
 // atomics ran at a tenth of the atomic rate: every adder hits the same rows):
