@@ -62,9 +62,10 @@ __global__ __launch_bounds__(NT) void small_to_big_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // features -> image (out_conv forward): y[b][co][h][w] = bias[co] + sum_{tap,cb} big[(h+kh-1,w+kw-1)][cb] * w[co][cb][tap]
 // Cb/8 lanes share one pixel (16 bytes of the feature row each) and reduce with shuffles.
+template <int Cs>   // image channels: compile-time, so the accumulators are registers and the channel loops unroll
 __global__ __launch_bounds__(NT) void big_to_small_kernel(const bf16_t* __restrict__ big, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                          int Cs, int H, int W, int Cb, int pix_per_block) {
+                                                          int H, int W, int Cb, int pix_per_block) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][Cs][Cb]
   for (int i = threadIdx.x; i < 9 * Cs * Cb; i += NT) {
     int tap = i / (Cs * Cb), r = i - tap * Cs * Cb, co = r / Cb, cb = r - co * Cb;
@@ -81,7 +82,9 @@ __global__ __launch_bounds__(NT) void big_to_small_kernel(const bf16_t* __restri
     const bool ok = m < m_end;
     const int mm = ok ? m : m_end - 1;
     const int b = mm / (H * W), r = mm - b * H * W, h = r / W, x = r - h * W;
-    float acc[MAXCS] = {0.f, 0.f, 0.f, 0.f};
+    float acc[Cs];
+#pragma unroll
+    for (int co = 0; co < Cs; ++co) acc[co] = 0.f;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(NT) void big_to_small_kernel(const bf16_t* __restri
         if (ih < 0 || iw < 0 || ih >= H || iw >= W) continue;
         float f[8];
         dm_unpack8(*(const bf16x8_t*)(big + ((size_t)(b * H + ih) * W + iw) * Cb + 8 * v), f);
+#pragma unroll
         for (int co = 0; co < Cs; ++co) {
           const float* wp = wl + ((kh * 3 + kw) * Cs + co) * Cb + 8 * v;
           const f32x4_t w0 = *(const f32x4_t*)wp, w1 = *(const f32x4_t*)(wp + 4);
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(NT) void big_to_small_kernel(const bf16_t* __restri
         }
       }
     }
+#pragma unroll
     for (int co = 0; co < Cs; ++co) {
       float t = acc[co];
       for (int o = VP >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
@@ -395,8 +400,16 @@ extern "C" int dm_out_conv_fwd(const void* h, const float* w, const float* bias,
   DM_REQUIRE(h && w && y, DM_ERR_ARG, "dm_out_conv_fwd: null argument");
   const int M = B * H * W, ppb = 256;
   DM_REQUIRE(9 * Cs * Cb * 4 <= 65536, DM_ERR_UNSUPPORTED, "dm_out_conv_fwd: %d x %d weights exceed 64 KiB of LDS", Cs, Cb);
-  hipLaunchKernelGGL(big_to_small_kernel, dim3(dm_cdiv(M, ppb)), dim3(NT), 9 * Cs * Cb * 4, (hipStream_t)stream,
-                     (const bf16_t*)h, w, bias, y, B, Cs, H, W, Cb, ppb);
+  const dim3 grid(dm_cdiv(M, ppb));
+  const int lds = 9 * Cs * Cb * 4;
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* hb = (const bf16_t*)h;
+  switch (Cs) {
+    case 1: hipLaunchKernelGGL(big_to_small_kernel<1>, grid, dim3(NT), lds, st, hb, w, bias, y, B, H, W, Cb, ppb); break;
+    case 2: hipLaunchKernelGGL(big_to_small_kernel<2>, grid, dim3(NT), lds, st, hb, w, bias, y, B, H, W, Cb, ppb); break;
+    case 3: hipLaunchKernelGGL(big_to_small_kernel<3>, grid, dim3(NT), lds, st, hb, w, bias, y, B, H, W, Cb, ppb); break;
+    default: hipLaunchKernelGGL(big_to_small_kernel<4>, grid, dim3(NT), lds, st, hb, w, bias, y, B, H, W, Cb, ppb); break;
+  }
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
