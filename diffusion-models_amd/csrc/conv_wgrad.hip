@@ -580,38 +580,47 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
   }
 }
 
-// Sums the slabs of one tile over the pixel slices and adds the sum to dw, in a fixed order: one workgroup per
-// (tile, 64 consecutive float4s of the slab); wave g sums slices g, g + 4, g + 8, ... (a slice is 1 KiB per wave
-// load), the four partial sums are added in wave order. Lane t of the 64 owns the float4 that thread (q, t2) of the
-// producing workgroups' first wave group held: 4 consecutive output channels of one input channel.
-__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(WgradArgs a) {
-  __shared__ f32x4_t red[3][64];
+// Sums the slabs of one tile over the pixel slices and adds the sum to dw, in a fixed order. A wave owns 64
+// consecutive float4s of a tile's slab (a slice is 1 KiB per wave load); G = 1, 2 or 4 waves of a workgroup share such
+// a chunk when there are enough slices - wave g sums slices g, g + G, ... and the partial sums are added in wave
+// order. Lane t of the 64 owns the float4 that thread (q, t2) of the producing workgroups' first wave group held:
+// 4 consecutive output channels of one input channel.
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(WgradArgs a, int G) {
+  __shared__ f32x4_t red[4][64];
   constexpr int F4 = SLAB_FLOATS / 4, CH = F4 / 64;   // float4s per slab, 64-float4 chunks per slab
   const int per = 3 * a.n_co_tiles * a.n_ci_tiles;
-  const int inner = blockIdx.x / CH, chunk = blockIdx.x - inner * CH;
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 4 + wave;
+  const int cid = unit / G, grp = unit - cid * G;      // chunk (over all tiles), slice group
+  const bool live = cid < per * CH;
+  const int inner = live ? cid / CH : 0, chunk = live ? cid - inner * CH : 0;
   const int e = chunk * 64 + lane;                     // float4 index in the slab = q * 256 + t2
   const f32x4_t* src = (const f32x4_t*)a.slabs + (size_t)inner * F4 + e;
   const size_t stride = (size_t)per * F4;
   f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  int ks = grp;
-  for (; ks + 12 < a.splitk; ks += 16) {
-    const f32x4_t v0 = src[(size_t)ks * stride], v1 = src[(size_t)(ks + 4) * stride];
-    const f32x4_t v2 = src[(size_t)(ks + 8) * stride], v3 = src[(size_t)(ks + 12) * stride];
-    sum += v0; sum += v1; sum += v2; sum += v3;
+  if (live) {
+    int ks = grp;
+    for (; ks + 3 * G < a.splitk; ks += 4 * G) {
+      const f32x4_t v0 = src[(size_t)ks * stride], v1 = src[(size_t)(ks + G) * stride];
+      const f32x4_t v2 = src[(size_t)(ks + 2 * G) * stride], v3 = src[(size_t)(ks + 3 * G) * stride];
+      sum += v0; sum += v1; sum += v2; sum += v3;
+    }
+    for (; ks < a.splitk; ks += G) sum += src[(size_t)ks * stride];
   }
-  for (; ks < a.splitk; ks += 4) sum += src[(size_t)ks * stride];
-  if (grp) red[grp - 1][lane] = sum;
-  __syncthreads();
-  if (grp) return;
-  sum += red[0][lane]; sum += red[1][lane]; sum += red[2][lane];
+  if (G > 1) {
+    red[wave][lane] = sum;
+    __syncthreads();
+    if (grp) return;
+    for (int g = 1; g < G; ++g) sum += red[wave + g][lane];
+  }
+  if (!live) return;
 
   const int q = e >> 8, t2 = e & 255;
   const int tiles = a.n_co_tiles * a.n_ci_tiles;
   const int kh = inner / tiles, rest = inner - kh * tiles;
   const int tco = rest / a.n_ci_tiles, tci = rest - tco * a.n_ci_tiles;
   const int t = q >> 3, i = (q >> 1) & 3, j = q & 1;
-  const int wave = t2 >> 6, l2 = t2 & 63, wm = wave >> 1, wn = wave & 1;
+  const int pw = t2 >> 6, l2 = t2 & 63, wm = pw >> 1, wn = pw & 1;
   const int co = tco * 128 + wm * 64 + i * 16 + (l2 >> 4) * 4;
   const int ci = tci * 64 + wn * 32 + j * 16 + (l2 & 15);
 #pragma unroll
@@ -717,7 +726,8 @@ static int wgrad_impl(const dm_conv_desc* d, const void* x1, const void* x2, con
   hipStream_t st = (hipStream_t)stream;
   if (row3 && a.slabs) {
     hipLaunchKernelGGL((conv_wgrad3_kernel<4, true>), grid, block, 0, st, a);
-    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(p.per * (SLAB_FLOATS / 256)), dim3(256), 0, st, a);
+    const int G = a.splitk >= 8 ? 4 : (a.splitk >= 4 ? 2 : 1);   // waves sharing a chunk: at least two slices each
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(dm_cdiv((long)p.per * (SLAB_FLOATS / 256) * G, 4)), dim3(256), 0, st, a, G);
   } else if (row3) hipLaunchKernelGGL((conv_wgrad3_kernel<4, false>), grid, block, 0, st, a);
   else if (wide_co && wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2>), grid, block, 0, st, a);
   else if (wide_co) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 4, 2>), grid, block, 0, st, a);
