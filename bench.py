@@ -31,6 +31,16 @@ FWD_GFLOP_PER_IMG = {"cos_cifar": 16.383, "beta_cifar": 16.383, "rf_cifar_long":
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
+def measured_conv_traffic():
+    """Average HBM-side bytes per forward/data-gradient conv launch, from profiles/r01_conv_traffic.json (rocprofv3
+    --pmc passes of this benchmark; counters cannot be read from inside the run). None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return round(json.load(f)["conv_fwd_dgrad_bytes_per_launch"])
+
+
 def load_cfg(name):
     with open(os.path.join(ROOT, "tests", "golden", "arg_json", name + ".json")) as f:
         return json.load(f)
@@ -77,13 +87,17 @@ class ConvTimer:
             d = desc._obj
             m = d.B * d.Ho * d.Wo
             flops = 2.0 * m * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
+            # algorithmic bytes: every operand once (input, weights, output, residual of the fused epilogue)
+            nbytes = 2.0 * (d.B * d.Hs * d.Ws * (d.C1 + d.C2) + d.Cout * d.KH * d.KW * (d.C1 + d.C2) + m * d.Cout)
+            if name == "dm_conv2d_igemm" and len(args) > 4 and args[4]:
+                nbytes += 2.0 * m * d.Cout
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = fn(desc, *args)
             e1.record()
             # the workspace form is the same operator (its time includes the reduce kernel)
             key = "dm_conv2d_wgrad" if name == "dm_conv2d_wgrad_ws" else name
-            self.records.append((key, flops, e0, e1, (d.B * d.Ho * d.Wo, d.Cout, d.C1 + d.C2, d.KH, d.stride, d.ups, d.transposed)))
+            self.records.append((key, flops, e0, e1, nbytes, (d.B * d.Ho * d.Wo, d.Cout, d.C1 + d.C2, d.KH, d.stride, d.ups, d.transposed)))
             return rc
         return call
 
@@ -95,14 +109,15 @@ class ConvTimer:
         torch.cuda.synchronize()
         out = {}
         dump = os.environ.get("DM_BENCH_DUMP_CONVS")
-        for name, flops, e0, e1, shape in self.records:
+        for name, flops, e0, e1, nbytes, shape in self.records:
             if dump:
                 ms = e0.elapsed_time(e1)
                 sys.stderr.write(f"[conv] {name[11:]:6s} M={shape[0]:6d} N={shape[1]:4d} C={shape[2]:4d} k={shape[3]} s={shape[4]} "
                                  f"ups={shape[5]} T={shape[6]} {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF\n")
-            s = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            s = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
             s["launches"] += 1
             s["flops"] += flops
+            s["bytes"] += nbytes
             s["ms"] += e0.elapsed_time(e1)
         return out
 
@@ -217,6 +232,9 @@ def main():
     ap.add_argument("--config", default="cos_cifar")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's batch_size)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a HIP graph")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="capture forward+backward and the optimizer tail as two graphs with the gradient all-reduce "
+                         "between them (what runs on more than one GPU; on one GPU for testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--mode", choices=["train", "sample"], default="train",
@@ -253,19 +271,37 @@ def main():
     for _ in range(3):
         run()
     torch.cuda.synchronize()
-    if not args.no_graph and world == 1:
+    split = world > 1 or args.split_graph
+    if not args.no_graph:
         try:
             ops.FORCE_REPACK = True
-            graph = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                run()  # warm-up on the capture stream
-                torch.cuda.synchronize()
-                with torch.cuda.graph(graph, stream=side):
-                    loss_static = step.step(x, cls)
+                if not split:
+                    graph = torch.cuda.CUDAGraph()
+                    run()  # warm-up on the capture stream
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(graph, stream=side):
+                        loss_static = step.step(x, cls)
+                    run = graph.replay
+                else:
+                    # More than one GPU: the two local phases are graphs, the bucketed all-reduce of the gradient
+                    # arena runs between them (collectives stay outside graph capture).
+                    graph, g_upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    step.forward_backward(x, cls); step.reduce(); step.update()  # warm-up on the capture stream
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(graph, stream=side):
+                        loss_static = step.forward_backward(x, cls)
+                    step.reduce()
+                    with torch.cuda.graph(g_upd, stream=side):
+                        step.update()
+
+                    def run():
+                        graph.replay()
+                        step.reduce()
+                        g_upd.replay()
             torch.cuda.current_stream().wait_stream(side)
-            run = graph.replay
         except Exception as e:  # capture is an optimisation; the eager path is the same kernels
             sys.stderr.write(f"[bench] graph capture failed, running eagerly: {e!r}\n")
             graph = None
@@ -308,7 +344,11 @@ def main():
             achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
                     "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                    # HBM-side bytes per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, averaged
+                    # over the same launches), beside the algorithmic bytes per launch of this run
+                    "traffic": measured_conv_traffic(), "traffic_unit": "bytes/launch",
+                    "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["launches"]),
                     "launches_per_step": ig["launches"], "ms_per_step": round(ig["ms"], 3),
                     "wgrad": {"achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2), "launches_per_step": wg["launches"],
                               "ms_per_step": round(wg["ms"], 3)} if wg and wg["ms"] > 0 else None}

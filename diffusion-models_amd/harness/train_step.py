@@ -155,10 +155,13 @@ class TrainStep:
                 self.reducer.on_ready(i)
 
     # ---- one step ----------------------------------------------------------------------------------------
-    def _backward_and_update(self, loss):
+    def _backward(self, loss, overlap=True):
+        """Backward into the gradient arena. overlap: launch each bucket's all-reduce as soon as it is complete
+        (eager multi-GPU steps); without it the collectives are left to _reduce(), so that this phase contains no
+        communication and can be captured into a HIP graph on every rank."""
         self.reducer.begin()
         self._in_backward = True
-        ops.DIRECT_GRADS, ops.GRAD_READY = True, (self._on_grad_ready if self.world > 1 else None)
+        ops.DIRECT_GRADS, ops.GRAD_READY = True, (self._on_grad_ready if (self.world > 1 and overlap) else None)
         ops.SIDE_WGRAD = int(self.side_wgrad)
         try:
             loss.backward()
@@ -169,7 +172,13 @@ class TrainStep:
             # the weight/bias gradient kernels ran on the second stream: join before anything reads the arena
             for side in ops.side_streams(self.arena.data.device):
                 torch.cuda.current_stream().wait_stream(side)
+
+    def _reduce(self):
+        """Finish the data-parallel mean of the gradient arena (launches whatever buckets are still outstanding)."""
         self.reducer.finish()
+
+    def _update(self):
+        """Clip, AdamW, EMA, bf16 weight mirrors, zero the gradients (train.py:441-450)."""
         a = self.arena
         st = torch.cuda.current_stream().cuda_stream
         if self.clip > 0:
@@ -186,6 +195,28 @@ class TrainStep:
         a.grad.zero_()
         self.steps += 1
         ops.WEIGHTS_EPOCH += 1  # packed bf16 copies of the weights are stale now
+
+    def _backward_and_update(self, loss):
+        self._backward(loss)
+        self._reduce()
+        self._update()
+
+    # ---- the step in three phases, for callers that capture the local phases into HIP graphs and keep the
+    # collectives outside them (bench.py on more than one GPU): forward_backward -> reduce -> update
+    def forward_backward(self, x, label=None):
+        uncond_mask = None
+        if label is not None:
+            uncond_mask = torch.bernoulli(self.p_uncond * torch.ones_like(label))
+        loss = self.scheduler.get_loss(x, self.model, cls=label, uncond_mask=uncond_mask)
+        self._backward(loss, overlap=False)
+        return loss.detach()
+
+    def reduce(self):
+        self.reducer.begin()
+        self._reduce()
+
+    def update(self):
+        self._update()
 
     def step(self, x, label=None):
         """train.py:429-452. Returns the loss tensor (device scalar; call .item() to mirror the reference's sync)."""
