@@ -402,8 +402,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, long s_co, long 
 }
 
 // ---- column sums
-__global__ __launch_bounds__(NT) void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long M,
-                                                         int C, int rows_per_block) {
+__global__ __launch_bounds__(NT) void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ out,
+                                                         float* __restrict__ out2, long M, int C, int rows_per_block) {
   // per-thread partial sums over this block's rows, combined across the block in LDS: one atomic per column per
   // block (many blocks adding to the same few addresses is what makes naive column sums slow)
   __shared__ float red[NT * 8];
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(NT) void colsum_bf16_kernel(const bf16_t* __restric
     float sum = 0.f;
     for (int q = 0; q < PL; ++q) sum += red[(q * VP + vv) * 8 + j];
     atomicAdd(out + col, sum);
+    if (out2) atomicAdd(out2 + col, sum);
   }
 }
 __global__ void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
@@ -659,14 +660,21 @@ extern "C" int dm_transpose_conv_weights(const void* src, void* dst, const dm_wt
   return DM_OK;
 }
 
-extern "C" int dm_colsum_bf16(const void* x, float* out, long M, int C, void* stream) {
+static int colsum_bf16(const void* x, float* out, float* out2, long M, int C, void* stream) {
   DM_REQUIRE(x && out && M > 0 && C > 0, DM_ERR_ARG, "dm_colsum_bf16: bad argument");
   DM_REQUIRE(C % 8 == 0 && C / 8 <= NT, DM_ERR_SHAPE, "dm_colsum_bf16: C=%d must be a multiple of 8 and <= %d", C, NT * 8);
   int rpb = 64;
   while (dm_cdiv(M, rpb) > 256) rpb *= 2;
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(dm_cdiv(M, rpb)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, out, M, C, rpb);
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(dm_cdiv(M, rpb)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, out, out2, M, C, rpb);
   DM_CHECK_LAUNCH();
   return DM_OK;
+}
+extern "C" int dm_colsum_bf16(const void* x, float* out, long M, int C, void* stream) {
+  return colsum_bf16(x, out, nullptr, M, C, stream);
+}
+extern "C" int dm_colsum_bf16_dual(const void* x, float* out, float* out2, long M, int C, void* stream) {
+  DM_REQUIRE(out2, DM_ERR_ARG, "dm_colsum_bf16_dual: null second output");
+  return colsum_bf16(x, out, out2, M, C, stream);
 }
 extern "C" int dm_colsum_f32(const float* x, float* out, int R, int C, void* stream) {
   DM_REQUIRE(x && out && R > 0 && C > 0, DM_ERR_ARG, "dm_colsum_f32: bad argument");

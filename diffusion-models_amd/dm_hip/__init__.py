@@ -51,6 +51,7 @@ _SIGNATURES = {
     "dm_pack_conv_weight": (c_int, [P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, P, P]),
     "dm_transpose_conv_weights": (c_int, [P, P, P, c_int, c_int, P]),
     "dm_colsum_bf16": (c_int, [P, P, c_long, c_int, P]),
+    "dm_colsum_bf16_dual": (c_int, [P, P, P, c_long, c_int, P]),
     "dm_colsum_f32": (c_int, [P, P, c_int, c_int, P]),
     "dm_in_conv_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dm_out_conv_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

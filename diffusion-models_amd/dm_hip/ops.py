@@ -169,7 +169,7 @@ class _ConvFn(Function):
     """y = conv2d(cat(x1, x2) [nearest-upsampled x2 if ups], weight) + bias + res"""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad=True):
+    def forward(ctx, x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad=True, bias_twin=None):
         _require_device(x1, "conv2d")
         x1 = as_nhwc(x1)
         x2 = as_nhwc(x2) if x2 is not None else None
@@ -191,6 +191,7 @@ class _ConvFn(Function):
                                   y.data_ptr(), _stream()))
         ctx.save_for_backward(x1, x2, weight)
         ctx.params = (weight, bias)
+        ctx.bias_twin = bias_twin
         ctx.cfg = (stride, pad, ups, pack, bias is not None and bias_grad, res is not None,
                    (B, C1, C2, Hs, Ws, Hi, Wi, Ho, Wo))
         return y
@@ -254,19 +255,31 @@ class _ConvFn(Function):
                     dw = dw.reshape(Cout, Cin)
         if want_db:
             dbf = bsink if bsink is not None else torch.zeros(Cout, dtype=torch.float32, device=dy.device)
-            check(lib.dm_colsum_bf16(dy.data_ptr(), dbf.data_ptr(), B * Ho * Wo, Cout, st_w))
+            twin = ctx.bias_twin
+            tsink = _grad_sink(twin) if (twin is not None and bsink is not None) else None
+            if tsink is not None:
+                # the twin's convolution produced the other term of the same sum (and ran with bias_grad=False)
+                check(lib.dm_colsum_bf16_dual(dy.data_ptr(), dbf.data_ptr(), tsink.data_ptr(), B * Ho * Wo, Cout, st_w))
+                _grad_done(twin)
+            else:
+                check(lib.dm_colsum_bf16(dy.data_ptr(), dbf.data_ptr(), B * Ho * Wo, Cout, st_w))
+                if twin is not None:
+                    g = dbf.detach().clone().to(twin.dtype)
+                    twin.grad = g if twin.grad is None else twin.grad + g
             if bsink is not None:
                 _grad_done(bparam)
             else:
                 db = dbf
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
-        return dx1, dx2, dw, db, dres, None, None, None, None, None
+        return dx1, dx2, dw, db, dres, None, None, None, None, None, None
 
 
-def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0, bias_grad=True):
-    """bias_grad=False: the bias is added but its gradient is left to the consumer of the output (group_norm_act's
+def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0, bias_grad=True, bias_twin=None):
+    """bias_twin: the bias parameter of another convolution whose output is added to this one's (run with
+    bias_grad=False): it receives this bias's gradient, the same column sums, from the same launch.
+    bias_grad=False: the bias is added but its gradient is left to the consumer of the output (group_norm_act's
     upstream_bias), which gets it for free."""
-    return _ConvFn.apply(x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad)
+    return _ConvFn.apply(x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad, bias_twin)
 
 
 # ------------------------------------------------------------------------------------------------------------

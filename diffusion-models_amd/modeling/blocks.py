@@ -107,9 +107,12 @@ class ConvBlock(nn.Module):
 
         if isinstance(self.res_proj, nn.Identity):
             res = x if skip is None else torch.cat([x, skip], dim=1)
-        else:
-            res = self.res_proj(x, x2=skip)
-        return self.conv2(h, res=res)
+            return self.conv2(h, res=res)
+        # res_proj's output and conv2's are the two terms of one sum: one launch of column sums over the block's
+        # output gradient serves both biases
+        twin = self.res_proj.bias if (self.res_proj.bias is not None and self.conv2.bias is not None) else None
+        res = self.res_proj(x, x2=skip, bias_grad=twin is None)
+        return self.conv2(h, res=res, bias_twin=twin)
 
 
 class DownsampleBlock(nn.Module):

@@ -23,9 +23,9 @@ class Conv2d(nn.Conv2d):
         self._pack = ops.WeightPack()
 
     def forward(self, x, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, ups: int = 0,
-                bias_grad: bool = True):
+                bias_grad: bool = True, bias_twin=None):
         return ops.conv2d(x, self.weight, self.bias, self._pack, x2=x2, res=res, stride=self.stride[0],
-                          pad=self._pad, ups=ups, bias_grad=bias_grad)
+                          pad=self._pad, ups=ups, bias_grad=bias_grad, bias_twin=bias_twin)
 
 
 class Linear(nn.Linear):

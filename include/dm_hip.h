@@ -97,6 +97,9 @@ int dm_transpose_conv_weights(const void* src, void* dst, const dm_wt_item* item
 
 /* out[c] += sum_m x[m][c]  (bias gradients; x bf16 [M][C], out fp32) */
 int dm_colsum_bf16(const void* x, float* out, long M, int C, void* stream);
+/* the same sums added into two outputs: a block's conv2 and res_proj (modeling/blocks.py:28,45,74-75) produce the
+ * two terms of one sum, so their bias gradients are the same column sums */
+int dm_colsum_bf16_dual(const void* x, float* out, float* out2, long M, int C, void* stream);
 /* out[c] += sum_r x[r][c]  (x fp32 [R][C]) */
 int dm_colsum_f32(const float* x, float* out, int R, int C, void* stream);
 

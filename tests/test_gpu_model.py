@@ -342,7 +342,8 @@ def test_step_in_phases_equals_step():
                 s_.reduce()
                 s_.update()
     torch.cuda.synchronize()
-    assert [float(v) for v in la] == [float(v) for v in lb]
+    assert float(la[0]) == float(lb[0])                            # same weights, same draws
+    assert abs(float(la[1]) - float(lb[1])) < 1e-5 * float(la[1])  # after one update (float-atomic bias/affine gradients)
     # parameter-side GroupNorm gradients are float atomics: equal up to summation order
     assert rel_err(b.arena.data, a.arena.data) < 1e-6 and rel_err(b.ema, a.ema) < 1e-6
     # the two phases as graphs, the reduction between them
