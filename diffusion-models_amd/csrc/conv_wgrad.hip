@@ -117,7 +117,7 @@ __device__ __forceinline__ void frag_wait(s16x4_t (&a)[2], s16x4_t (&b)[2], s16x
 // or all 64 (KG = 1), so each SIMD holds KG waves that hide each other's LDS latency. The tiles move through a ring
 // of NST LDS stages filled by buffer_load ... lds NST-1 steps ahead; a step waits only for its own stage (counted
 // vmcnt; steps beyond the end still issue their loads, out of range = zero fill, to keep the count fixed).
-template <int TCO, int TCI, int NST, int KG>
+template <int TCO, int TCI, int NST, int KG, bool SLAB = false>
 __global__ __launch_bounds__(256 * KG, 1) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int NT = 256 * KG;
   using TY = Tile<TCO, NT>;
@@ -299,12 +299,64 @@ __global__ __launch_bounds__(256 * KG, 1) void conv_wgrad_kernel(WgradArgs a) {
     }
     __syncthreads();
   }
+  if constexpr (SLAB) {
+    // with a workspace: the partial tile leaves row-major with plain 16-byte stores; wgrad_reduce_kernel adds up
+    f32x4_t* slab = (f32x4_t*)a.slabs + (size_t)logical * (TCO * TCI / 4);
+    for (int item = tid; item < TCO * TCI / 4; item += NT) {
+      const int row = item / (TCI / 4), c4 = item - row * (TCI / 4);
+      slab[item] = *(const f32x4_t*)(ep + row * EP_PITCH + c4 * 4);
+    }
+    return;
+  }
   const int T = a.KH * a.KW;
   for (int item = tid; item < TCO * TCI; item += NT) {
     int row = item / TCI, col = item - row * TCI;
     int co = co0 + row, ci = ci0 + col;
     if (co < a.Cout)
       atomicAdd(a.dw + ((size_t)co * T + tap) * a.Cin + ci, ep[row * EP_PITCH + col]);
+  }
+}
+
+// Sum of the row-major 128 x 128 slabs of one (tap, tile) over the pixel slices, added to dw: a wave owns 64
+// consecutive float4s of the tile, G waves of a workgroup share them (wave g sums slices g, g + G, ...; fixed order).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int G) {
+  __shared__ f32x4_t red[4][64];
+  constexpr int TCO = 128, TCI = 128, F4 = TCO * TCI / 4, CH = F4 / 64;
+  const int T = a.KH * a.KW;
+  const int per = T * a.n_co_tiles * a.n_ci_tiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 4 + wave;
+  const int cid = unit / G, grp = unit - cid * G;
+  const bool live = cid < per * CH;
+  const int inner = live ? cid / CH : 0, chunk = live ? cid - inner * CH : 0;
+  const int e = chunk * 64 + lane;
+  const f32x4_t* src = (const f32x4_t*)a.slabs + (size_t)inner * F4 + e;
+  const size_t stride = (size_t)per * F4;
+  f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    int ks = grp;
+    for (; ks + 3 * G < a.splitk; ks += 4 * G) {
+      const f32x4_t v0 = src[(size_t)ks * stride], v1 = src[(size_t)(ks + G) * stride];
+      const f32x4_t v2 = src[(size_t)(ks + 2 * G) * stride], v3 = src[(size_t)(ks + 3 * G) * stride];
+      sum += v0; sum += v1; sum += v2; sum += v3;
+    }
+    for (; ks < a.splitk; ks += G) sum += src[(size_t)ks * stride];
+  }
+  if (G > 1) {
+    red[wave][lane] = sum;
+    __syncthreads();
+    if (grp) return;
+    for (int g = 1; g < G; ++g) sum += red[wave + g][lane];
+  }
+  if (!live) return;
+  const int tiles = a.n_co_tiles * a.n_ci_tiles;
+  const int tap = inner / tiles, rest = inner - tap * tiles;
+  const int tco = rest / a.n_ci_tiles, tci = rest - tco * a.n_ci_tiles;
+  const int row = e / (TCI / 4), c4 = e - row * (TCI / 4);
+  const int co = tco * TCO + row, ci = tci * TCI + c4 * 4;
+  if (co < a.Cout) {
+    f32x4_t* dst = (f32x4_t*)(a.dw + ((size_t)co * T + tap) * a.Cin + ci);
+    *dst = *dst + sum;
   }
 }
 
@@ -650,9 +702,9 @@ static WgradPlan make_plan(const dm_conv_desc* d, bool slabs) {
   const int Cin = d->C1 + d->C2;
   p.row3 = g_dm_use_wgrad3 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Wo >= 8 &&
            BKM % d->Wo == 0 && M % BKM == 0 && (BKM / d->Wo) * (d->Wo + 2) <= 128;
-  slabs = slabs && p.row3;
   p.wide_co = d->Cout % 128 == 0;
   p.wide_ci = d->C1 % 128 == 0 && d->C2 % 128 == 0;
+  slabs = slabs && (p.row3 || (p.wide_co && p.wide_ci));   // kernels that can leave their partial tiles as slabs
   const int tco = (p.wide_co || p.row3) ? 128 : 64, tci = (p.wide_ci && !p.row3) ? 128 : 64;
   p.n_co_tiles = dm_cdiv(d->Cout, tco);
   p.n_ci_tiles = Cin / tci;
@@ -667,7 +719,8 @@ static WgradPlan make_plan(const dm_conv_desc* d, bool slabs) {
   // the fixed cost (pipeline fill, partial tile out) counted as OVERHEAD steps - about 30 with partial-tile atomics
   // (measured with cold caches), far less when the partial tile leaves as a slab.
   const int OVERHEAD = slabs ? g_dm_wgrad_slab_overhead : 30;
-  const int max_split = steps_total / 8 > 0 ? (steps_total / 8 < 64 ? steps_total / 8 : 64) : 1;
+  const int cap = slabs ? 128 : 64;
+  const int max_split = steps_total / 8 > 0 ? (steps_total / 8 < cap ? steps_total / 8 : cap) : 1;
   int splitk = 1;
   long best = -1;
   for (int sk = 1; sk <= max_split; ++sk) {
@@ -677,7 +730,7 @@ static WgradPlan make_plan(const dm_conv_desc* d, bool slabs) {
   p.rows_per_split = dm_cdiv(steps_total, splitk) * BKM;
   p.splitk = dm_cdiv(M, p.rows_per_split);
   p.n_blocks = p.splitk * p.per;
-  p.ws_bytes = slabs ? (size_t)p.n_blocks * SLAB_FLOATS * sizeof(float) : 0;
+  p.ws_bytes = slabs ? (size_t)p.n_blocks * (p.row3 ? SLAB_FLOATS : 128 * 128) * sizeof(float) : 0;
   return p;
 }
 
@@ -729,7 +782,11 @@ static int wgrad_impl(const dm_conv_desc* d, const void* x1, const void* x2, con
     const int G = a.splitk >= 8 ? 4 : (a.splitk >= 4 ? 2 : 1);   // waves sharing a chunk: at least two slices each
     hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(dm_cdiv((long)p.per * (SLAB_FLOATS / 256) * G, 4)), dim3(256), 0, st, a, G);
   } else if (row3) hipLaunchKernelGGL((conv_wgrad3_kernel<4, false>), grid, block, 0, st, a);
-  else if (wide_co && wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2>), grid, block, 0, st, a);
+  else if (wide_co && wide_ci && a.slabs) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2, true>), grid, block, 0, st, a);
+    const int G = a.splitk >= 8 ? 4 : (a.splitk >= 4 ? 2 : 1);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dm_cdiv((long)p.per * (128 * 128 / 256) * G, 4)), dim3(256), 0, st, a, G);
+  } else if (wide_co && wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2>), grid, block, 0, st, a);
   else if (wide_co) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 4, 2>), grid, block, 0, st, a);
   else if (wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, 2>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 4, 2>), grid, block, 0, st, a);

@@ -68,7 +68,8 @@ int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const
 
 /* The same with a caller-provided scratch workspace (16-byte aligned, at least dm_conv2d_wgrad_ws_bytes(d) bytes,
  * contents irrelevant on entry and on return; null / 0 selects the call above). Where the layer has a slab path
- * (3x3, stride 1, pad 1, output width 8..64 dividing 64), the split-K partial tiles go to the workspace with plain
+ * (3x3, stride 1, pad 1, output width 8..64 dividing 64; or any layer whose input channels per source and output
+ * channels are multiples of 128), the split-K partial tiles go to the workspace with plain
  * stores and a second kernel adds their sum to dw: no float atomics, and a result that does not depend on the
  * order in which workgroups finish. dm_conv2d_wgrad_ws_bytes returns 0 for layers without that path.
  * Same operator as above: the weight gradient autograd computes for nn.Conv2d of modeling/blocks.py:26,28,110

@@ -109,13 +109,15 @@ def _conv2d_case(B, C1, C2, Cout, H, W, k, stride, ups):
     assert rel_err(resd.grad.float(), resr.grad) < 1e-6
 
 
-@pytest.mark.parametrize("B,C1,C2,Cout,H,W,ups", [
-    (64, 128, 0, 128, 32, 32, 0),     # many pixel slices per tile
-    (32, 64, 64, 192, 16, 16, 0),     # two sources, Cout not a multiple of the 128-channel tile
-    (16, 128, 0, 64, 8, 8, 1),        # fused upsample, half-empty output-channel tile
-    (2, 64, 0, 64, 8, 8, 0),          # a single slice
+@pytest.mark.parametrize("B,C1,C2,Cout,H,W,ups,k", [
+    (64, 128, 0, 128, 32, 32, 0, 3),     # many pixel slices per tile
+    (32, 64, 64, 192, 16, 16, 0, 3),     # two sources, Cout not a multiple of the 128-channel tile
+    (16, 128, 0, 64, 8, 8, 1, 3),        # fused upsample, half-empty output-channel tile
+    (2, 64, 0, 64, 8, 8, 0, 3),          # a single slice
+    (64, 256, 128, 128, 32, 32, 0, 1),   # 1x1 over two sources: the single-tap kernel's slab path (128 x 128 tiles)
+    (8, 128, 0, 256, 16, 16, 0, 1),
 ])
-def test_conv2d_wgrad_workspace(B, C1, C2, Cout, H, W, ups):
+def test_conv2d_wgrad_workspace(B, C1, C2, Cout, H, W, ups, k):
     """The slab path of the weight gradient (partial tiles to a workspace, summed by a second kernel) against the
     atomic path on the same inputs; it accumulates into dw like the atomic path, leaves dw alone outside the
     tensor, and gives bit-identical results from run to run (sums in slice order)."""
@@ -130,11 +132,11 @@ def test_conv2d_wgrad_workspace(B, C1, C2, Cout, H, W, ups):
     x1 = torch.randn(B, H, W, C1, generator=g).to(bf).to(d_)
     x2 = torch.randn(B, H, W, C2, generator=g).to(bf).to(d_) if C2 else None
     dy = torch.randn(B, Ho, Wo, Cout, generator=g).to(bf).to(d_)
-    desc = ConvDesc(B, H, W, C1, C2, Cout, 3, 3, 1, 1, ups, 0, Ho, Wo)
+    desc = ConvDesc(B, H, W, C1, C2, Cout, k, k, 1, (k - 1) // 2, ups, 0, Ho, Wo)
     p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     nbytes = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(desc))
-    assert nbytes > 0 and nbytes % (3 * 128 * 64 * 4) == 0
-    base = torch.randn(Cout * 9 * Cin + 64, generator=g).to(d_)       # dw accumulates; 64 guard floats behind it
+    assert nbytes > 0 and nbytes % ((3 * 128 * 64 if k == 3 else 128 * 128) * 4) == 0
+    base = torch.randn(Cout * k * k * Cin + 64, generator=g).to(d_)       # dw accumulates; 64 guard floats behind it
     ref = base.clone()
     check(lib.dm_conv2d_wgrad(ctypes.byref(desc), p(x1), p(x2), p(dy), ref.data_ptr(), st))
     outs = []
