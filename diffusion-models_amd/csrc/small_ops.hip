@@ -664,7 +664,9 @@ static int colsum_bf16(const void* x, float* out, float* out2, long M, int C, vo
   DM_REQUIRE(x && out && M > 0 && C > 0, DM_ERR_ARG, "dm_colsum_bf16: bad argument");
   DM_REQUIRE(C % 8 == 0 && C / 8 <= NT, DM_ERR_SHAPE, "dm_colsum_bf16: C=%d must be a multiple of 8 and <= %d", C, NT * 8);
   int rpb = 64;
-  while (dm_cdiv(M, rpb) > 256) rpb *= 2;
+  // every workgroup ends with one float atomic per column into the same C addresses: beyond ~64 adders the
+  // contention costs more than the extra workgroups bring (measured inside the training step: 64 beats 32, 128, 256)
+  while (dm_cdiv(M, rpb) > 64) rpb *= 2;
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(dm_cdiv(M, rpb)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, out, out2, M, C, rpb);
   DM_CHECK_LAUNCH();
   return DM_OK;
