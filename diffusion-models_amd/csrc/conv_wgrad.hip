@@ -22,6 +22,7 @@
 
 extern int g_dm_use_wgrad3;
 extern int g_dm_wgrad_slab_overhead;
+extern int g_dm_wgrad_reduce_cap;
 
 namespace {
 
@@ -325,38 +326,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int G) {
   const int T = a.KH * a.KW;
   const int per = T * a.n_co_tiles * a.n_ci_tiles;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int unit = blockIdx.x * 4 + wave;
-  const int cid = unit / G, grp = unit - cid * G;
-  const bool live = cid < per * CH;
-  const int inner = live ? cid / CH : 0, chunk = live ? cid - inner * CH : 0;
-  const int e = chunk * 64 + lane;
-  const f32x4_t* src = (const f32x4_t*)a.slabs + (size_t)inner * F4 + e;
-  const size_t stride = (size_t)per * F4;
-  f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  if (live) {
-    int ks = grp;
-    for (; ks + 3 * G < a.splitk; ks += 4 * G) {
-      const f32x4_t v0 = src[(size_t)ks * stride], v1 = src[(size_t)(ks + G) * stride];
-      const f32x4_t v2 = src[(size_t)(ks + 2 * G) * stride], v3 = src[(size_t)(ks + 3 * G) * stride];
-      sum += v0; sum += v1; sum += v2; sum += v3;
+  const int units = per * CH * G;
+  for (int u0 = blockIdx.x * 4; u0 < units; u0 += gridDim.x * 4) {
+    const int unit = u0 + wave;
+    const int cid = unit / G, grp = unit - cid * G;
+    const bool live = cid < per * CH;
+    const int inner = live ? cid / CH : 0, chunk = live ? cid - inner * CH : 0;
+    const int e = chunk * 64 + lane;
+    const f32x4_t* src = (const f32x4_t*)a.slabs + (size_t)inner * F4 + e;
+    const size_t stride = (size_t)per * F4;
+    f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      int ks = grp;
+      for (; ks + 3 * G < a.splitk; ks += 4 * G) {
+        const f32x4_t v0 = src[(size_t)ks * stride], v1 = src[(size_t)(ks + G) * stride];
+        const f32x4_t v2 = src[(size_t)(ks + 2 * G) * stride], v3 = src[(size_t)(ks + 3 * G) * stride];
+        sum += v0; sum += v1; sum += v2; sum += v3;
+      }
+      for (; ks < a.splitk; ks += G) sum += src[(size_t)ks * stride];
     }
-    for (; ks < a.splitk; ks += G) sum += src[(size_t)ks * stride];
-  }
-  if (G > 1) {
-    red[wave][lane] = sum;
-    __syncthreads();
-    if (grp) return;
-    for (int g = 1; g < G; ++g) sum += red[wave + g][lane];
-  }
-  if (!live) return;
-  const int tiles = a.n_co_tiles * a.n_ci_tiles;
-  const int tap = inner / tiles, rest = inner - tap * tiles;
-  const int tco = rest / a.n_ci_tiles, tci = rest - tco * a.n_ci_tiles;
-  const int row = e / (TCI / 4), c4 = e - row * (TCI / 4);
-  const int co = tco * TCO + row, ci = tci * TCI + c4 * 4;
-  if (co < a.Cout) {
-    f32x4_t* dst = (f32x4_t*)(a.dw + ((size_t)co * T + tap) * a.Cin + ci);
-    *dst = *dst + sum;
+    if (G > 1) {
+      __syncthreads();
+      red[wave][lane] = sum;
+      __syncthreads();
+      if (grp == 0)
+        for (int g = 1; g < G; ++g) sum += red[wave + g][lane];
+    }
+    if (!live || grp) continue;
+    const int tiles = a.n_co_tiles * a.n_ci_tiles;
+    const int tap = inner / tiles, rest = inner - tap * tiles;
+    const int tco = rest / a.n_ci_tiles, tci = rest - tco * a.n_ci_tiles;
+    const int row = e / (TCI / 4), c4 = e - row * (TCI / 4);
+    const int co = tco * TCO + row, ci = tci * TCI + c4 * 4;
+    if (co < a.Cout) {
+      f32x4_t* dst = (f32x4_t*)(a.dw + ((size_t)co * T + tap) * a.Cin + ci);
+      *dst = *dst + sum;
+    }
   }
 }
 
@@ -642,42 +647,47 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(WgradArgs a, int G) 
   constexpr int F4 = SLAB_FLOATS / 4, CH = F4 / 64;   // float4s per slab, 64-float4 chunks per slab
   const int per = 3 * a.n_co_tiles * a.n_ci_tiles;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int unit = blockIdx.x * 4 + wave;
-  const int cid = unit / G, grp = unit - cid * G;      // chunk (over all tiles), slice group
-  const bool live = cid < per * CH;
-  const int inner = live ? cid / CH : 0, chunk = live ? cid - inner * CH : 0;
-  const int e = chunk * 64 + lane;                     // float4 index in the slab = q * 256 + t2
-  const f32x4_t* src = (const f32x4_t*)a.slabs + (size_t)inner * F4 + e;
-  const size_t stride = (size_t)per * F4;
-  f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  if (live) {
-    int ks = grp;
-    for (; ks + 3 * G < a.splitk; ks += 4 * G) {
-      const f32x4_t v0 = src[(size_t)ks * stride], v1 = src[(size_t)(ks + G) * stride];
-      const f32x4_t v2 = src[(size_t)(ks + 2 * G) * stride], v3 = src[(size_t)(ks + 3 * G) * stride];
-      sum += v0; sum += v1; sum += v2; sum += v3;
+  const int units = per * CH * G;
+  // a capped grid walks the (chunk, slice group) units; every wave of a workgroup makes the same number of rounds
+  for (int u0 = blockIdx.x * 4; u0 < units; u0 += gridDim.x * 4) {
+    const int unit = u0 + wave;
+    const int cid = unit / G, grp = unit - cid * G;      // chunk (over all tiles), slice group
+    const bool live = cid < per * CH;
+    const int inner = live ? cid / CH : 0, chunk = live ? cid - inner * CH : 0;
+    const int e = chunk * 64 + lane;                     // float4 index in the slab = q * 256 + t2
+    const f32x4_t* src = (const f32x4_t*)a.slabs + (size_t)inner * F4 + e;
+    const size_t stride = (size_t)per * F4;
+    f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      int ks = grp;
+      for (; ks + 3 * G < a.splitk; ks += 4 * G) {
+        const f32x4_t v0 = src[(size_t)ks * stride], v1 = src[(size_t)(ks + G) * stride];
+        const f32x4_t v2 = src[(size_t)(ks + 2 * G) * stride], v3 = src[(size_t)(ks + 3 * G) * stride];
+        sum += v0; sum += v1; sum += v2; sum += v3;
+      }
+      for (; ks < a.splitk; ks += G) sum += src[(size_t)ks * stride];
     }
-    for (; ks < a.splitk; ks += G) sum += src[(size_t)ks * stride];
-  }
-  if (G > 1) {
-    red[wave][lane] = sum;
-    __syncthreads();
-    if (grp) return;
-    for (int g = 1; g < G; ++g) sum += red[wave + g][lane];
-  }
-  if (!live) return;
+    if (G > 1) {
+      __syncthreads();   // the previous round's partial sums have been consumed
+      red[wave][lane] = sum;
+      __syncthreads();
+      if (grp == 0)
+        for (int g = 1; g < G; ++g) sum += red[wave + g][lane];
+    }
+    if (!live || grp) continue;
 
-  const int q = e >> 8, t2 = e & 255;
-  const int tiles = a.n_co_tiles * a.n_ci_tiles;
-  const int kh = inner / tiles, rest = inner - kh * tiles;
-  const int tco = rest / a.n_ci_tiles, tci = rest - tco * a.n_ci_tiles;
-  const int t = q >> 3, i = (q >> 1) & 3, j = q & 1;
-  const int pw = t2 >> 6, l2 = t2 & 63, wm = pw >> 1, wn = pw & 1;
-  const int co = tco * 128 + wm * 64 + i * 16 + (l2 >> 4) * 4;
-  const int ci = tci * 64 + wn * 32 + j * 16 + (l2 & 15);
+    const int q = e >> 8, t2 = e & 255;
+    const int tiles = a.n_co_tiles * a.n_ci_tiles;
+    const int kh = inner / tiles, rest = inner - kh * tiles;
+    const int tco = rest / a.n_ci_tiles, tci = rest - tco * a.n_ci_tiles;
+    const int t = q >> 3, i = (q >> 1) & 3, j = q & 1;
+    const int pw = t2 >> 6, l2 = t2 & 63, wm = pw >> 1, wn = pw & 1;
+    const int co = tco * 128 + wm * 64 + i * 16 + (l2 >> 4) * 4;
+    const int ci = tci * 64 + wn * 32 + j * 16 + (l2 & 15);
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-    if (co + r < a.Cout) a.dw[((size_t)(co + r) * 9 + kh * 3 + t) * a.Cin + ci] += sum[r];
+    for (int r = 0; r < 4; ++r)
+      if (co + r < a.Cout) a.dw[((size_t)(co + r) * 9 + kh * 3 + t) * a.Cin + ci] += sum[r];
+  }
 }
 
 void make_magic(unsigned d, unsigned& magic, unsigned& shift) {
@@ -695,6 +705,12 @@ struct WgradPlan {
   int n_co_tiles, n_ci_tiles, per, splitk, rows_per_split, n_blocks;
   size_t ws_bytes;   // workspace the slab path needs (0: this layer has no slab path)
 };
+
+// workgroups of a slab-sum kernel for `units` wave-sized work items (four per workgroup), capped
+static int reduce_grid(long units) {
+  const long g = (units + 3) / 4;
+  return (int)(g < g_dm_wgrad_reduce_cap ? g : g_dm_wgrad_reduce_cap);
+}
 
 static WgradPlan make_plan(const dm_conv_desc* d, bool slabs) {
   WgradPlan p;
@@ -780,12 +796,12 @@ static int wgrad_impl(const dm_conv_desc* d, const void* x1, const void* x2, con
   if (row3 && a.slabs) {
     hipLaunchKernelGGL((conv_wgrad3_kernel<4, true>), grid, block, 0, st, a);
     const int G = a.splitk >= 8 ? 4 : (a.splitk >= 4 ? 2 : 1);   // waves sharing a chunk: at least two slices each
-    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(dm_cdiv((long)p.per * (SLAB_FLOATS / 256) * G, 4)), dim3(256), 0, st, a, G);
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(reduce_grid((long)p.per * (SLAB_FLOATS / 256) * G)), dim3(256), 0, st, a, G);
   } else if (row3) hipLaunchKernelGGL((conv_wgrad3_kernel<4, false>), grid, block, 0, st, a);
   else if (wide_co && wide_ci && a.slabs) {
     hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2, true>), grid, block, 0, st, a);
     const int G = a.splitk >= 8 ? 4 : (a.splitk >= 4 ? 2 : 1);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dm_cdiv((long)p.per * (128 * 128 / 256) * G, 4)), dim3(256), 0, st, a, G);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid((long)p.per * (128 * 128 / 256) * G)), dim3(256), 0, st, a, G);
   } else if (wide_co && wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2>), grid, block, 0, st, a);
   else if (wide_co) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 4, 2>), grid, block, 0, st, a);
   else if (wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, 2>), grid, block, 0, st, a);

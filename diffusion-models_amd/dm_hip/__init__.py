@@ -104,3 +104,10 @@ def check(rc):
     """Map a non-zero dm_status to an exception carrying the library's message."""
     if rc != 0:
         raise DmHipError(f"libdm_hip status {rc}: {lib.dm_last_error().decode()}")
+
+
+# DM_HIP_CONFIG="key=value,key=value": run-time switches of the library (dm_config_set) from the environment, for
+# tuning runs; unknown keys are errors.
+for _kv in filter(None, os.environ.get("DM_HIP_CONFIG", "").split(",")):
+    _k, _, _v = _kv.partition("=")
+    check(lib.dm_config_set(_k.strip().encode(), int(_v)))
