@@ -51,45 +51,13 @@ __global__ __launch_bounds__(NT) void adamw_ema_kernel(float* __restrict__ p, co
   const float step_size = lr / bc1;
   const float sqrt_bc2 = sqrtf(bc2);
   const float omd = 1.f - ema_decay;
-  const bool vec_ok = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) == 0 && ((uintptr_t)wb & 7) == 0;
-  auto update = [&](float gv, float pv, float mv, float vv, float& po, float& mo, float& vo) {
-    const float gi = gv * clip;
-    float pi = pv * (1.f - lr * wd);
-    const float mi = mv + (1.f - b1) * (gi - mv);
-    const float vi = b2 * vv + (1.f - b2) * gi * gi;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const float gi = g[i] * clip;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     const float denom = sqrtf(vi) / sqrt_bc2 + eps;
     pi -= step_size * (mi / denom);
-    po = pi; mo = mi; vo = vi;
-  };
-  // 16 bytes per lane and array (the arenas are 16-byte aligned); the last n % 4 elements one by one
-  const long n4 = vec_ok ? n >> 2 : 0;
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
-    const f32x4_t g4 = ((const f32x4_t*)g)[i], p4 = ((const f32x4_t*)p)[i], m4 = ((const f32x4_t*)m)[i], v4 = ((const f32x4_t*)v)[i];
-    f32x4_t po, mo, vo;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float a, b, c;
-      update(g4[j], p4[j], m4[j], v4[j], a, b, c);
-      po[j] = a; mo[j] = b; vo[j] = c;
-    }
-    ((f32x4_t*)p)[i] = po; ((f32x4_t*)m)[i] = mo; ((f32x4_t*)v)[i] = vo;
-    if (ema) {
-      f32x4_t e4 = ((const f32x4_t*)ema)[i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) e4[j] = e4[j] - omd * (e4[j] - po[j]);
-      ((f32x4_t*)ema)[i] = e4;
-    }
-    if (wb) {
-      typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
-      bf16x4_t w4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w4[j] = (bf16_t)po[j];
-      ((bf16x4_t*)wb)[i] = w4;
-    }
-  }
-  for (long i = (n4 << 2) + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
-    float pi, mi, vi;
-    update(g[i], p[i], m[i], v[i], pi, mi, vi);
     p[i] = pi; m[i] = mi; v[i] = vi;
     if (ema) { const float e = ema[i]; ema[i] = e - omd * (e - pi); }
     if (wb) wb[i] = (bf16_t)pi;
@@ -146,8 +114,8 @@ extern "C" int dm_adamw_ema_step(float* p, const float* g, float* m, float* v, f
                                  float bc2, float ema_decay, const float* hyper, void* stream) {
   DM_REQUIRE(p && g && m && v && n > 0, DM_ERR_ARG, "dm_adamw_ema_step: bad argument");
   DM_REQUIRE(!(max_norm > 0.f) || norm, DM_ERR_ARG, "dm_adamw_ema_step: clipping needs the norm");
-  long gl = ((n >> 2) + NT - 1) / NT;
-  int grid = (int)(gl > 4096 ? 4096 : (gl < 1 ? 1 : gl));
+  long gl = (n + NT - 1) / NT;
+  int grid = (int)(gl > 4096 ? 4096 : gl);
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16_t*)w_bf16, norm,
                      max_norm, n, lr, b1, b2, eps, wd, bc1, bc2, ema_decay, hyper);
   DM_CHECK_LAUNCH();
