@@ -591,6 +591,7 @@ class _InConvFn(Function):
         y = empty_nhwc(B, Cb, H, W, x.device)
         check(lib.dm_in_conv_fwd(x32.data_ptr(), w32.data_ptr(), _p(b32), y.data_ptr(), B, Cs, H, W, Cb, _stream()))
         ctx.save_for_backward(x32)
+        ctx.params = (weight, bias)
         ctx.cfg = (B, Cs, H, W, Cb, bias is not None)
         return y
 
@@ -601,10 +602,39 @@ class _InConvFn(Function):
         if ctx.needs_input_grad[0]:
             raise RuntimeError("in_conv: gradient w.r.t. the image is not implemented (the reference never needs it)")
         dy = as_nhwc(dy)
-        dw = torch.zeros((Cb, Cs, 3, 3), dtype=torch.float32, device=dy.device)
-        db = torch.zeros((Cb,), dtype=torch.float32, device=dy.device) if has_bias else None
-        check(lib.dm_edge_conv_wgrad(x32.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(db), B, Cs, H, W, Cb, 1, _stream()))
+        weight, bias = ctx.params
+        dw, db = _edge_wgrad(x32, dy, weight, bias, (B, Cs, H, W, Cb), True, (x32, dy))
         return None, dw, db
+
+
+def _edge_wgrad(small, big, weight, bias, shape, big_is_output, wait_for):
+    """Weight/bias gradient of an edge convolution: straight into the parameters' gradient buffers and on the side
+    stream when the caller set those modes up (as the other convolutions do), else as fresh tensors for autograd."""
+    B, Cs, H, W, Cb = shape
+    dev = big.device
+    wsink = _grad_sink(weight)
+    bsink = _grad_sink(bias) if bias is not None else None
+    direct = wsink is not None and (bias is None or bsink is not None)
+    wshape = (Cb, Cs, 3, 3) if big_is_output else (Cs, Cb, 3, 3)
+    dw = wsink if direct else torch.zeros(wshape, dtype=torch.float32, device=dev)
+    db = None
+    if bias is not None:
+        db = bsink if direct else torch.zeros((Cb if big_is_output else Cs,), dtype=torch.float32, device=dev)
+    st = _stream()
+    if direct and SIDE_WGRAD:
+        side = side_stream(dev, 0)
+        side.wait_stream(torch.cuda.current_stream())
+        for t in wait_for:
+            t.record_stream(side)
+        st = side.cuda_stream
+    check(lib.dm_edge_conv_wgrad(small.data_ptr(), big.data_ptr(), dw.data_ptr(), _p(db), B, Cs, H, W, Cb,
+                                 1 if big_is_output else 0, st))
+    if direct:
+        _grad_done(weight)
+        if bias is not None:
+            _grad_done(bias)
+        return None, None
+    return dw, db
 
 
 def in_conv(x, weight, bias):
@@ -625,6 +655,7 @@ class _OutConvFn(Function):
         y = torch.empty((B, Cs, H, W), dtype=torch.float32, device=h.device)
         check(lib.dm_out_conv_fwd(h.data_ptr(), w32.data_ptr(), _p(b32), y.data_ptr(), B, Cs, H, W, Cb, _stream()))
         ctx.save_for_backward(h, w32)
+        ctx.params = (weight, bias)
         ctx.cfg = (B, Cs, H, W, Cb, bias is not None)
         return y
 
@@ -639,9 +670,8 @@ class _OutConvFn(Function):
             dh = empty_nhwc(B, Cb, H, W, dy.device)
             check(lib.dm_out_conv_dgrad(dy.data_ptr(), w32.data_ptr(), dh.data_ptr(), B, Cs, H, W, Cb, st))
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros((Cs, Cb, 3, 3), dtype=torch.float32, device=dy.device)
-            db = torch.zeros((Cs,), dtype=torch.float32, device=dy.device) if has_bias else None
-            check(lib.dm_edge_conv_wgrad(dy.data_ptr(), h.data_ptr(), dw.data_ptr(), _p(db), B, Cs, H, W, Cb, 0, st))
+            weight, bias = ctx.params
+            dw, db = _edge_wgrad(dy, h, weight, bias, (B, Cs, H, W, Cb), False, (dy, h))
         return dh, dw, db
 
 
