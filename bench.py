@@ -77,7 +77,7 @@ class ConvTimer:
         self.records = []
 
     def __enter__(self):
-        self._orig = {n: getattr(self.lib, n) for n in ("dm_conv2d_igemm", "dm_conv2d_wgrad", "dm_conv2d_wgrad_ws")}
+        self._orig = {n: getattr(self.lib, n) for n in ("dm_conv2d_igemm", "dm_conv2d_wgrad")}
         for name, fn in self._orig.items():
             setattr(self.lib, name, self._wrap(name, fn))
         return self
@@ -95,9 +95,8 @@ class ConvTimer:
             e0.record()
             rc = fn(desc, *args)
             e1.record()
-            # the workspace form is the same operator (its time includes the reduce kernel)
-            key = "dm_conv2d_wgrad" if name == "dm_conv2d_wgrad_ws" else name
-            self.records.append((key, flops, e0, e1, nbytes, (d.B * d.Ho * d.Wo, d.Cout, d.C1 + d.C2, d.KH, d.stride, d.ups, d.transposed)))
+            # (the weight gradient's time includes its slab-sum kernel)
+            self.records.append((name, flops, e0, e1, nbytes, (d.B * d.Ho * d.Wo, d.Cout, d.C1 + d.C2, d.KH, d.stride, d.ups, d.transposed)))
             return rc
         return call
 

@@ -10,14 +10,13 @@
 // transposing read land on different banks.
 //
 // One workgroup = one (tap, 128|64 output channels, 128|64 input channels) tile over one slice of the pixel
-// axis (split-K); partial tiles are transposed through LDS and added with 256-byte-contiguous fp32 atomics
-// into dw, which therefore ACCUMULATES (callers zero it or keep the running gradient in it).
+// axis (split-K). dw ACCUMULATES (callers zero it or keep the running gradient in it).
 //
 // Float atomics execute at the memory side at about 1.3 TB/s chip-wide, a fifth of the plain-store rate, and one
-// round of workgroups adds a whole CU-full of accumulators (25 MB): with a caller-provided workspace the 3-tap
-// kernel therefore stores each partial tile as a slab (plain 16-byte stores, in accumulator-register order) and
-// a second, light kernel sums the slabs of a tile in slice order and adds the sum to dw - which also makes the
-// result independent of arrival order (bitwise reproducible).
+// round of workgroups adds a whole CU-full of accumulators (25 MB): every kernel therefore stores its partial tile
+// as a slab in a caller-provided workspace (plain 16-byte stores) and a second, light kernel sums the slabs of a
+// tile in slice order and adds the sum to dw - which also makes the result independent of arrival order (bitwise
+// reproducible). There is no atomic path.
 #include "dm_common.h"
 
 extern int g_dm_use_wgrad3;
@@ -118,7 +117,7 @@ __device__ __forceinline__ void frag_wait(s16x4_t (&a)[2], s16x4_t (&b)[2], s16x
 // or all 64 (KG = 1), so each SIMD holds KG waves that hide each other's LDS latency. The tiles move through a ring
 // of NST LDS stages filled by buffer_load ... lds NST-1 steps ahead; a step waits only for its own stage (counted
 // vmcnt; steps beyond the end still issue their loads, out of range = zero fill, to keep the count fixed).
-template <int TCO, int TCI, int NST, int KG, bool SLAB = false>
+template <int TCO, int TCI, int NST, int KG>
 __global__ __launch_bounds__(256 * KG, 1) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int NT = 256 * KG;
   using TY = Tile<TCO, NT>;
@@ -280,7 +279,8 @@ __global__ __launch_bounds__(256 * KG, 1) void conv_wgrad_kernel(WgradArgs a) {
     compute();
   }
 
-  // ---- epilogue: sum the wave groups and transpose through LDS, then row-contiguous fp32 atomics
+  // ---- epilogue: sum the wave groups and transpose through LDS; the partial tile leaves row-major with plain
+  // 16-byte stores (wgrad_reduce_kernel adds the slabs of a tile up)
   wait_vmcnt<0>();  // the trailing zero-fill loads must have landed before LDS is reused
   __syncthreads();
   float* ep = (float*)smem;
@@ -300,29 +300,19 @@ __global__ __launch_bounds__(256 * KG, 1) void conv_wgrad_kernel(WgradArgs a) {
     }
     __syncthreads();
   }
-  if constexpr (SLAB) {
-    // with a workspace: the partial tile leaves row-major with plain 16-byte stores; wgrad_reduce_kernel adds up
-    f32x4_t* slab = (f32x4_t*)a.slabs + (size_t)logical * (TCO * TCI / 4);
-    for (int item = tid; item < TCO * TCI / 4; item += NT) {
-      const int row = item / (TCI / 4), c4 = item - row * (TCI / 4);
-      slab[item] = *(const f32x4_t*)(ep + row * EP_PITCH + c4 * 4);
-    }
-    return;
-  }
-  const int T = a.KH * a.KW;
-  for (int item = tid; item < TCO * TCI; item += NT) {
-    int row = item / TCI, col = item - row * TCI;
-    int co = co0 + row, ci = ci0 + col;
-    if (co < a.Cout)
-      atomicAdd(a.dw + ((size_t)co * T + tap) * a.Cin + ci, ep[row * EP_PITCH + col]);
+  f32x4_t* slab = (f32x4_t*)a.slabs + (size_t)logical * (TCO * TCI / 4);
+  for (int item = tid; item < TCO * TCI / 4; item += NT) {
+    const int row = item / (TCI / 4), c4 = item - row * (TCI / 4);
+    slab[item] = *(const f32x4_t*)(ep + row * EP_PITCH + c4 * 4);
   }
 }
 
-// Sum of the row-major 128 x 128 slabs of one (tap, tile) over the pixel slices, added to dw: a wave owns 64
+// Sum of the row-major TCO x TCI slabs of one (tap, tile) over the pixel slices, added to dw: a wave owns 64
 // consecutive float4s of the tile, G waves of a workgroup share them (wave g sums slices g, g + G, ...; fixed order).
+template <int TCO, int TCI>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int G) {
   __shared__ f32x4_t red[4][64];
-  constexpr int TCO = 128, TCI = 128, F4 = TCO * TCI / 4, CH = F4 / 64;
+  constexpr int F4 = TCO * TCI / 4, CH = F4 / 64;
   const int T = a.KH * a.KW;
   const int per = T * a.n_co_tiles * a.n_ci_tiles;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -389,7 +379,7 @@ __device__ __forceinline__ void read_tr(s16x4_t& v, unsigned addr) {
 
 constexpr int SLAB_FLOATS = 3 * 128 * 64;   // one partial tile of the 3-tap kernel
 
-template <int NST, bool SLAB>
+template <int NST>
 __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
   constexpr int NT = 512, TCO = 128, TCI = 64;
   using TY = Tile<TCO, NT>;                       // dy tile: 64 pixels x 128 channels
@@ -397,9 +387,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
   constexpr int STAGE = TY::BYTES + XBYTES;
   constexpr int XPIECES = XBYTES / 16 / NT;       // 2 per thread
   constexpr int LPS = TY::PIECES + XPIECES;
-  constexpr int EP_PITCH = TCI + 4;
-  constexpr int EP_TAP = TCO * EP_PITCH;          // floats per tap in the epilogue buffer
-  constexpr int TOTAL = (NST * STAGE > 3 * EP_TAP * 4) ? NST * STAGE : 3 * EP_TAP * 4;
+  constexpr int EP_BYTES = 24 * 256 * 16;         // epilogue: one wave group's accumulators (24 float4 per thread)
+  constexpr int TOTAL = (NST * STAGE > EP_BYTES) ? NST * STAGE : EP_BYTES;
   constexpr int MI = 4, NJ = 2;                   // wave tile 64 (co) x 32 (ci)
   __shared__ __attribute__((aligned(16))) char smem[TOTAL];
 
@@ -580,60 +569,30 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
 
   wait_vmcnt<0>();
   __syncthreads();
-  if constexpr (SLAB) {
-    // ---- epilogue with a workspace: sum the two wave groups through LDS in accumulator-register order (float4
-    // q = (tap, i, j) of thread t at [q][t]: conflict-free 16-byte accesses) and store the slab with plain stores
-    f32x4_t* ep4 = (f32x4_t*)smem;
-    const int t2 = tid & 255;
-    if (kg == 1) {
+  // ---- epilogue: sum the two wave groups through LDS in accumulator-register order (float4 q = (tap, i, j) of
+  // thread t at [q][t]: conflict-free 16-byte accesses) and store the slab with plain stores
+  f32x4_t* ep4 = (f32x4_t*)smem;
+  const int t2 = tid & 255;
+  if (kg == 1) {
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) ep4[((t * MI + i) * NJ + j) * 256 + t2] = acc[t][i][j];
-    }
-    __syncthreads();
-    if (kg == 0) {
-      f32x4_t* slab = (f32x4_t*)a.slabs + (size_t)logical * (SLAB_FLOATS / 4);
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const int q = (t * MI + i) * NJ + j;
-            slab[q * 256 + t2] = ep4[q * 256 + t2] + acc[t][i][j];
-          }
-    }
-    return;
+        for (int j = 0; j < NJ; ++j) ep4[((t * MI + i) * NJ + j) * 256 + t2] = acc[t][i][j];
   }
-  // ---- epilogue without: sum the wave groups and transpose through LDS (one buffer per tap), then fp32 atomics
-  float* ep = (float*)smem;
-  const int frow = lane & 15, fq = lane >> 4;
+  __syncthreads();
+  if (kg == 0) {
+    f32x4_t* slab = (f32x4_t*)a.slabs + (size_t)logical * (SLAB_FLOATS / 4);
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    if (kg == g) {
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float* e = ep + t * EP_TAP + (wm * 64 + i * 16 + fq * 4 + r) * EP_PITCH + wn * 32 + j * 16 + frow;
-              *e = (g == 0) ? acc[t][i][j][r] : *e + acc[t][i][j][r];
-            }
-    }
-    __syncthreads();
-  }
-  for (int item = tid; item < 3 * TCO * TCI; item += NT) {
-    const int t = item / (TCO * TCI), r2 = item - t * (TCO * TCI);
-    const int row = r2 / TCI, col = r2 - row * TCI;
-    const int co = co0 + row, ci = ci0 + col;
-    if (co < a.Cout)
-      atomicAdd(a.dw + ((size_t)co * 9 + kh * 3 + t) * a.Cin + ci, ep[t * EP_TAP + row * EP_PITCH + col]);
+        for (int j = 0; j < NJ; ++j) {
+          const int q = (t * MI + i) * NJ + j;
+          slab[q * 256 + t2] = ep4[q * 256 + t2] + acc[t][i][j];
+        }
   }
 }
 
@@ -699,11 +658,11 @@ void make_magic(unsigned d, unsigned& magic, unsigned& shift) {
 
 }  // namespace
 
-// The launch plan of a layer: kernel variant, tiles and pixel-axis split. `slabs`: partial tiles go to a workspace.
+// The launch plan of a layer: kernel variant, tiles and pixel-axis split.
 struct WgradPlan {
   bool row3, wide_co, wide_ci;
   int n_co_tiles, n_ci_tiles, per, splitk, rows_per_split, n_blocks;
-  size_t ws_bytes;   // workspace the slab path needs (0: this layer has no slab path)
+  size_t ws_bytes;   // workspace for the partial tiles
 };
 
 // workgroups of a slab-sum kernel for `units` wave-sized work items (four per workgroup), capped
@@ -712,7 +671,7 @@ static int reduce_grid(long units) {
   return (int)(g < g_dm_wgrad_reduce_cap ? g : g_dm_wgrad_reduce_cap);
 }
 
-static WgradPlan make_plan(const dm_conv_desc* d, bool slabs) {
+static WgradPlan make_plan(const dm_conv_desc* d) {
   WgradPlan p;
   const long M = (long)d->B * d->Ho * d->Wo;
   const int Cin = d->C1 + d->C2;
@@ -720,7 +679,6 @@ static WgradPlan make_plan(const dm_conv_desc* d, bool slabs) {
            BKM % d->Wo == 0 && M % BKM == 0 && (BKM / d->Wo) * (d->Wo + 2) <= 128;
   p.wide_co = d->Cout % 128 == 0;
   p.wide_ci = d->C1 % 128 == 0 && d->C2 % 128 == 0;
-  slabs = slabs && (p.row3 || (p.wide_co && p.wide_ci));   // kernels that can leave their partial tiles as slabs
   const int tco = (p.wide_co || p.row3) ? 128 : 64, tci = (p.wide_ci && !p.row3) ? 128 : 64;
   p.n_co_tiles = dm_cdiv(d->Cout, tco);
   p.n_ci_tiles = Cin / tci;
@@ -732,10 +690,9 @@ static WgradPlan make_plan(const dm_conv_desc* d, bool slabs) {
     return n > 0 ? n : 256;
   }();
   // Split the pixel axis to minimise rounds x (steps per workgroup + fixed cost): one workgroup per CU per round,
-  // the fixed cost (pipeline fill, partial tile out) counted as OVERHEAD steps - about 30 with partial-tile atomics
-  // (measured with cold caches), far less when the partial tile leaves as a slab.
-  const int OVERHEAD = slabs ? g_dm_wgrad_slab_overhead : 30;
-  const int cap = slabs ? 128 : 64;
+  // the fixed cost (pipeline fill, partial tile out) counted as OVERHEAD steps.
+  const int OVERHEAD = g_dm_wgrad_slab_overhead;
+  const int cap = 128;
   const int max_split = steps_total / 8 > 0 ? (steps_total / 8 < cap ? steps_total / 8 : cap) : 1;
   int splitk = 1;
   long best = -1;
@@ -746,13 +703,24 @@ static WgradPlan make_plan(const dm_conv_desc* d, bool slabs) {
   p.rows_per_split = dm_cdiv(steps_total, splitk) * BKM;
   p.splitk = dm_cdiv(M, p.rows_per_split);
   p.n_blocks = p.splitk * p.per;
-  p.ws_bytes = slabs ? (size_t)p.n_blocks * (p.row3 ? SLAB_FLOATS : 128 * 128) * sizeof(float) : 0;
+  p.ws_bytes = (size_t)p.n_blocks * (p.row3 ? SLAB_FLOATS : tco * tci) * sizeof(float);
   return p;
 }
 
-static int wgrad_impl(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, void* ws,
-                      size_t ws_bytes, void* stream) {
-  DM_REQUIRE(d && x1 && dy && dw, DM_ERR_ARG, "dm_conv2d_wgrad: null argument");
+extern "C" size_t dm_conv2d_wgrad_ws_bytes(const dm_conv_desc* d) {
+  return d ? make_plan(d).ws_bytes : 0;
+}
+
+template <int TCO, int TCI>
+static void launch_single_tap(const WgradArgs& a, const WgradPlan& p, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, 4, 2>), grid, dim3(512), 0, st, a);
+  const int G = a.splitk >= 8 ? 4 : (a.splitk >= 4 ? 2 : 1);   // waves sharing a chunk: at least two slices each
+  hipLaunchKernelGGL((wgrad_reduce_kernel<TCO, TCI>), dim3(reduce_grid((long)p.per * (TCO * TCI / 256) * G)), dim3(256), 0, st, a, G);
+}
+
+extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, void* ws,
+                               size_t ws_bytes, void* stream) {
+  DM_REQUIRE(d && x1 && dy && dw && ws, DM_ERR_ARG, "dm_conv2d_wgrad: null argument");
   DM_REQUIRE(d->C1 > 0 && d->C1 % 64 == 0 && d->C2 >= 0 && d->C2 % 64 == 0, DM_ERR_SHAPE,
              "dm_conv2d_wgrad: input channels (%d, %d) must be multiples of 64", d->C1, d->C2);
   DM_REQUIRE((d->C2 == 0) == (x2 == nullptr), DM_ERR_ARG, "dm_conv2d_wgrad: x2 and C2 disagree");
@@ -784,43 +752,22 @@ static int wgrad_impl(const dm_conv_desc* d, const void* x1, const void* x2, con
   a.dh_step = (BKM % (d->Ho * d->Wo)) / d->Wo;
   a.dw_step = (BKM % (d->Ho * d->Wo)) % d->Wo;
 
-  const WgradPlan p = make_plan(d, ws != nullptr);
-  DM_REQUIRE(ws_bytes >= p.ws_bytes, DM_ERR_ARG, "dm_conv2d_wgrad_ws: workspace of %zu bytes, %zu needed", ws_bytes, p.ws_bytes);
-  DM_REQUIRE(((uintptr_t)ws) % 16 == 0, DM_ERR_ARG, "dm_conv2d_wgrad_ws: workspace must be 16-byte aligned");
-  const bool row3 = p.row3, wide_co = p.wide_co, wide_ci = p.wide_ci;
+  const WgradPlan p = make_plan(d);
+  DM_REQUIRE(ws_bytes >= p.ws_bytes, DM_ERR_ARG, "dm_conv2d_wgrad: workspace of %zu bytes, %zu needed", ws_bytes, p.ws_bytes);
+  DM_REQUIRE(((uintptr_t)ws) % 16 == 0, DM_ERR_ARG, "dm_conv2d_wgrad: workspace must be 16-byte aligned");
   a.n_co_tiles = p.n_co_tiles; a.n_ci_tiles = p.n_ci_tiles;
   a.rows_per_split = p.rows_per_split; a.splitk = p.splitk; a.n_blocks = p.n_blocks;
-  a.slabs = p.ws_bytes ? (float*)ws : nullptr;
-  dim3 grid((a.n_blocks + 7) / 8 * 8), block(512);
+  a.slabs = (float*)ws;
+  dim3 grid((a.n_blocks + 7) / 8 * 8);
   hipStream_t st = (hipStream_t)stream;
-  if (row3 && a.slabs) {
-    hipLaunchKernelGGL((conv_wgrad3_kernel<4, true>), grid, block, 0, st, a);
-    const int G = a.splitk >= 8 ? 4 : (a.splitk >= 4 ? 2 : 1);   // waves sharing a chunk: at least two slices each
-    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(reduce_grid((long)p.per * (SLAB_FLOATS / 256) * G)), dim3(256), 0, st, a, G);
-  } else if (row3) hipLaunchKernelGGL((conv_wgrad3_kernel<4, false>), grid, block, 0, st, a);
-  else if (wide_co && wide_ci && a.slabs) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2, true>), grid, block, 0, st, a);
+  if (p.row3) {
+    hipLaunchKernelGGL((conv_wgrad3_kernel<4>), grid, dim3(512), 0, st, a);
     const int G = a.splitk >= 8 ? 4 : (a.splitk >= 4 ? 2 : 1);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid((long)p.per * (128 * 128 / 256) * G)), dim3(256), 0, st, a, G);
-  } else if (wide_co && wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2>), grid, block, 0, st, a);
-  else if (wide_co) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 4, 2>), grid, block, 0, st, a);
-  else if (wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 4, 2>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 4, 2>), grid, block, 0, st, a);
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(reduce_grid((long)p.per * (SLAB_FLOATS / 256) * G)), dim3(256), 0, st, a, G);
+  } else if (p.wide_co && p.wide_ci) launch_single_tap<128, 128>(a, p, grid, st);
+  else if (p.wide_co) launch_single_tap<128, 64>(a, p, grid, st);
+  else if (p.wide_ci) launch_single_tap<64, 128>(a, p, grid, st);
+  else launch_single_tap<64, 64>(a, p, grid, st);
   DM_CHECK_LAUNCH();
   return DM_OK;
-}
-
-extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,
-                               void* stream) {
-  return wgrad_impl(d, x1, x2, dy, dw, nullptr, 0, stream);
-}
-
-extern "C" size_t dm_conv2d_wgrad_ws_bytes(const dm_conv_desc* d) {
-  return d ? make_plan(d, true).ws_bytes : 0;
-}
-
-extern "C" int dm_conv2d_wgrad_ws(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,
-                                  void* ws, size_t ws_bytes, void* stream) {
-  DM_REQUIRE(ws || ws_bytes == 0, DM_ERR_ARG, "dm_conv2d_wgrad_ws: null workspace with a size");
-  return wgrad_impl(d, x1, x2, dy, dw, ws, ws_bytes, stream);
 }

@@ -12,7 +12,7 @@ void dm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dm_last_error(void) { return g_err; }
-extern "C" int dm_abi_version(void) { return 1; }
+extern "C" int dm_abi_version(void) { return 2; }
 
 // run-time switches (tests exercise both convolution paths)
 int g_dm_use_patch_kernel = 1;

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NT) void big_to_small_kernel(const bf16_t* __restri
 constexpr int WG_PIX = 64;
 template <int CS>
 __global__ __launch_bounds__(NT) void edge_wgrad_kernel(const float* __restrict__ small, const bf16_t* __restrict__ big,
-                                                        float* __restrict__ dw, float* __restrict__ dbias, int B, int H,
+                                                        float* __restrict__ part, int want_bias, int B, int H,
                                                         int W, int Cb, int big_is_output, int pix_per_block) {
   constexpr int K = CS * 9;
   constexpr int KP = (K + 1 + 3) / 4 * 4;  // taps + a column of ones (bias), padded to float4
@@ -178,16 +178,30 @@ __global__ __launch_bounds__(NT) void edge_wgrad_kernel(const float* __restrict_
       }
     }
   }
-  if (pg < NPG) {
+  // this workgroup's partial sums: the pixel groups of a channel are added in group order through LDS, then plain
+  // stores into the workgroup's row of the partial buffer (laid out like dw, the bias terms behind it)
+  float* mine = part + (size_t)blockIdx.x * (K * Cb + (want_bias ? (big_is_output ? Cb : CS) : 0));
+  {
+    float* red = lds;   // [NT]
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int cs = k / 9, tap = k - cs * 9;
-      const size_t o = big_is_output ? ((size_t)(cb * CS + cs) * 9 + tap) : ((size_t)(cs * Cb + cb) * 9 + tap);
-      atomicAdd(dw + o, acc[k]);
+    for (int k = 0; k <= K; ++k) {
+      __syncthreads();
+      red[threadIdx.x] = acc[k];
+      __syncthreads();
+      if (pg == 0) {
+        float t = 0.f;
+        for (int q = 0; q < NPG; ++q) t += red[q * Cb + cb];
+        if (k < K) {
+          const int cs = k / 9, tap = k - cs * 9;
+          const size_t o = big_is_output ? ((size_t)(cb * CS + cs) * 9 + tap) : ((size_t)(cs * Cb + cb) * 9 + tap);
+          mine[o] = t;
+        } else if (big_is_output && want_bias) {
+          mine[K * Cb + cb] = t;
+        }
+      }
     }
-    if (big_is_output && dbias) atomicAdd(dbias + cb, acc[K]);
   }
-  if (!big_is_output && dbias) {
+  if (!big_is_output && want_bias) {
     // out_conv bias: sum of the image-side gradient itself = centre tap (kh = kw = 1) of each channel
     __syncthreads();
     float* red = lds;
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(NT) void edge_wgrad_kernel(const float* __restrict_
       if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * CS + cs] = t;
     }
     __syncthreads();
-    if (threadIdx.x < CS) atomicAdd(dbias + threadIdx.x, red[threadIdx.x] + red[CS + threadIdx.x] + red[2 * CS + threadIdx.x] + red[3 * CS + threadIdx.x]);
+    if (threadIdx.x < CS) mine[K * Cb + threadIdx.x] = red[threadIdx.x] + red[CS + threadIdx.x] + red[2 * CS + threadIdx.x] + red[3 * CS + threadIdx.x];
   }
 }
 
@@ -215,10 +229,11 @@ __global__ __launch_bounds__(NT) void edge_wgrad_kernel(const float* __restrict_
 // is a skinny GEMM with the pixels as reduction axis. Per 64-pixel step the feature rows go to LDS as they lie in
 // memory ([pixel][cb], 32-byte units XOR-swizzled by row) and are read with the transposing ds_read_b64_tr_b16;
 // S is built k-major ([k][pixel], bf16 - the precision the image side has under autocast) so its fragments are
-// plain 16-byte reads. One workgroup = 4 waves x (Cb/4 feature channels) over a run of pixels; fp32 atomics at the end.
+// plain 16-byte reads. One workgroup = 4 waves x (Cb/4 feature channels) over a run of pixels; each workgroup leaves
+// its partial sums in its own row of a scratch buffer and an ordered sum adds the rows to dw (no float atomics).
 template <int CS, int CB>
 __global__ __launch_bounds__(NT) void edge_wgrad_mfma_kernel(const float* __restrict__ small, const bf16_t* __restrict__ big,
-                                                             float* __restrict__ dw, float* __restrict__ dbias, int B, int H,
+                                                             float* __restrict__ part, int want_bias, int B, int H,
                                                              int W, int big_is_output, int pix_per_block) {
   constexpr int K = CS * 9;
   constexpr int NTILE = (K + 1 + 15) / 16;      // 16-column tiles of D
@@ -308,7 +323,9 @@ __global__ __launch_bounds__(NT) void edge_wgrad_mfma_kernel(const float* __rest
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   }
-  // D: lane holds column k = 16 j + (lane & 15), rows cb = wave * CB/4 + 16 i + 4 (lane >> 4) + r
+  // D: lane holds column k = 16 j + (lane & 15), rows cb = wave * CB/4 + 16 i + 4 (lane >> 4) + r; every element has
+  // one owner, so the workgroup's partial sums leave with plain stores (laid out like dw, the bias terms behind it)
+  float* mine = part + (size_t)blockIdx.x * (K * CB + (want_bias ? (big_is_output ? CB : CS) : 0));
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -320,13 +337,13 @@ __global__ __launch_bounds__(NT) void edge_wgrad_mfma_kernel(const float* __rest
         if (k < K) {
           const int cs = k / 9, tap = k - cs * 9;
           const size_t o = big_is_output ? ((size_t)(cb * CS + cs) * 9 + tap) : ((size_t)(cs * CB + cb) * 9 + tap);
-          atomicAdd(dw + o, acc[i][j][r]);
-        } else if (k == K && big_is_output && dbias) {
-          atomicAdd(dbias + cb, acc[i][j][r]);
+          mine[o] = acc[i][j][r];
+        } else if (k == K && big_is_output && want_bias) {
+          mine[K * CB + cb] = acc[i][j][r];
         }
       }
     }
-  if (!big_is_output && dbias) {
+  if (!big_is_output && want_bias) {
     // out_conv bias: sum of the image-side gradient itself
     __shared__ float red[4 * CS];
     float part[CS];
@@ -343,19 +360,33 @@ __global__ __launch_bounds__(NT) void edge_wgrad_mfma_kernel(const float* __rest
       if (lane == 0) red[wave * CS + cs] = t;
     }
     __syncthreads();
-    if (tid < CS) atomicAdd(dbias + tid, red[tid] + red[CS + tid] + red[2 * CS + tid] + red[3 * CS + tid]);
+    if (tid < CS) mine[K * CB + tid] = red[tid] + red[CS + tid] + red[2 * CS + tid] + red[3 * CS + tid];
   }
 }
 
+// pixels per workgroup of the two weight-gradient kernels
+bool edge_wgrad_on_mfma(int W, int Cb) { return (Cb == 64 || Cb == 128) && W % 8 == 0; }
+int edge_wgrad_ppb(long M, int W, int Cb) {
+  if (edge_wgrad_on_mfma(W, Cb)) {
+    int ppb = 512;
+    while (ppb > 64 && dm_cdiv(M, ppb) < 256) ppb /= 2;
+    return ppb;
+  }
+  int ppb = 1024;
+  while (ppb > WG_PIX && dm_cdiv(M, ppb) < 128) ppb /= 2;
+  return ppb;
+}
+int edge_wgrad_veclen(int Cs, int Cb, int big_is_output, bool bias) {
+  return Cs * 9 * Cb + (bias ? (big_is_output ? Cb : Cs) : 0);
+}
+
 template <int CS>
-void launch_edge_wgrad_mfma(const float* small, const bf16_t* big, float* dw, float* dbias, int B, int H, int W, int Cb,
-                            int big_is_output, hipStream_t st) {
+void launch_edge_wgrad_mfma(const float* small, const bf16_t* big, float* part, int want_bias, int B, int H, int W, int Cb,
+                            int big_is_output, int ppb, hipStream_t st) {
   const int M = B * H * W;
-  int ppb = 512;
-  while (ppb > 64 && dm_cdiv(M, ppb) < 256) ppb /= 2;
   dim3 grid(dm_cdiv(M, ppb)), block(NT);
-  if (Cb == 128) hipLaunchKernelGGL((edge_wgrad_mfma_kernel<CS, 128>), grid, block, 0, st, small, big, dw, dbias, B, H, W, big_is_output, ppb);
-  else hipLaunchKernelGGL((edge_wgrad_mfma_kernel<CS, 64>), grid, block, 0, st, small, big, dw, dbias, B, H, W, big_is_output, ppb);
+  if (Cb == 128) hipLaunchKernelGGL((edge_wgrad_mfma_kernel<CS, 128>), grid, block, 0, st, small, big, part, want_bias, B, H, W, big_is_output, ppb);
+  else hipLaunchKernelGGL((edge_wgrad_mfma_kernel<CS, 64>), grid, block, 0, st, small, big, part, want_bias, B, H, W, big_is_output, ppb);
 }
 
 int check_edge(const char* who, int B, int Cs, int H, int W, int Cb) {
@@ -414,37 +445,46 @@ extern "C" int dm_out_conv_fwd(const void* h, const float* w, const float* bias,
   return DM_OK;
 }
 
+extern "C" long dm_edge_conv_wgrad_ws_floats(int B, int Cs, int H, int W, int Cb, int big_is_output) {
+  if (B <= 0 || Cs <= 0 || H <= 0 || W <= 0 || Cb <= 0) return 0;
+  const long M = (long)B * H * W;
+  return (long)dm_cdiv(M, edge_wgrad_ppb(M, W, Cb)) * edge_wgrad_veclen(Cs, Cb, big_is_output, true);
+}
+
 extern "C" int dm_edge_conv_wgrad(const float* small, const void* big, float* dw, float* dbias, int B, int Cs, int H,
-                                  int W, int Cb, int big_is_output, void* stream) {
+                                  int W, int Cb, int big_is_output, float* ws, void* stream) {
   int rc = check_edge("dm_edge_conv_wgrad", B, Cs, H, W, Cb);
   if (rc) return rc;
-  DM_REQUIRE(small && big && dw, DM_ERR_ARG, "dm_edge_conv_wgrad: null argument");
+  DM_REQUIRE(small && big && dw && ws, DM_ERR_ARG, "dm_edge_conv_wgrad: null argument");
   DM_REQUIRE(Cb <= 256, DM_ERR_UNSUPPORTED, "dm_edge_conv_wgrad: feature width %d > 256", Cb);
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* bg = (const bf16_t*)big;
-  if ((Cb == 64 || Cb == 128) && W % 8 == 0) {
+  const int M = B * H * W;
+  const int ppb = edge_wgrad_ppb(M, W, Cb), nblocks = dm_cdiv(M, ppb);
+  const int want_bias = dbias != nullptr;
+  const int n = edge_wgrad_veclen(Cs, Cb, big_is_output, want_bias);
+  if (edge_wgrad_on_mfma(W, Cb)) {
     switch (Cs) {
-      case 1: launch_edge_wgrad_mfma<1>(small, bg, dw, dbias, B, H, W, Cb, big_is_output, st); break;
-      case 2: launch_edge_wgrad_mfma<2>(small, bg, dw, dbias, B, H, W, Cb, big_is_output, st); break;
-      case 3: launch_edge_wgrad_mfma<3>(small, bg, dw, dbias, B, H, W, Cb, big_is_output, st); break;
-      default: launch_edge_wgrad_mfma<4>(small, bg, dw, dbias, B, H, W, Cb, big_is_output, st); break;
+      case 1: launch_edge_wgrad_mfma<1>(small, bg, ws, want_bias, B, H, W, Cb, big_is_output, ppb, st); break;
+      case 2: launch_edge_wgrad_mfma<2>(small, bg, ws, want_bias, B, H, W, Cb, big_is_output, ppb, st); break;
+      case 3: launch_edge_wgrad_mfma<3>(small, bg, ws, want_bias, B, H, W, Cb, big_is_output, ppb, st); break;
+      default: launch_edge_wgrad_mfma<4>(small, bg, ws, want_bias, B, H, W, Cb, big_is_output, ppb, st); break;
     }
     DM_CHECK_LAUNCH();
-    return DM_OK;
+  } else {
+    const int kp = (Cs * 9 + 1 + 3) / 4 * 4;
+    const int lds = (WG_PIX * kp + WG_PIX * Cb) * 4;
+    DM_REQUIRE(lds <= 65536, DM_ERR_UNSUPPORTED, "dm_edge_conv_wgrad: feature width %d exceeds 64 KiB of LDS", Cb);
+    dim3 grid(nblocks), block(NT);
+    switch (Cs) {
+      case 1: hipLaunchKernelGGL(edge_wgrad_kernel<1>, grid, block, lds, st, small, bg, ws, want_bias, B, H, W, Cb, big_is_output, ppb); break;
+      case 2: hipLaunchKernelGGL(edge_wgrad_kernel<2>, grid, block, lds, st, small, bg, ws, want_bias, B, H, W, Cb, big_is_output, ppb); break;
+      case 3: hipLaunchKernelGGL(edge_wgrad_kernel<3>, grid, block, lds, st, small, bg, ws, want_bias, B, H, W, Cb, big_is_output, ppb); break;
+      default: hipLaunchKernelGGL(edge_wgrad_kernel<4>, grid, block, lds, st, small, bg, ws, want_bias, B, H, W, Cb, big_is_output, ppb); break;
+    }
+    DM_CHECK_LAUNCH();
   }
-  const int M = B * H * W;
-  int ppb = 1024;
-  while (ppb > WG_PIX && dm_cdiv(M, ppb) < 128) ppb /= 2;
-  const int kp = (Cs * 9 + 1 + 3) / 4 * 4;
-  const int lds = (WG_PIX * kp + WG_PIX * Cb) * 4;
-  DM_REQUIRE(lds <= 65536, DM_ERR_UNSUPPORTED, "dm_edge_conv_wgrad: feature width %d exceeds 64 KiB of LDS", Cb);
-  dim3 grid(dm_cdiv(M, ppb)), block(NT);
-  switch (Cs) {
-    case 1: hipLaunchKernelGGL(edge_wgrad_kernel<1>, grid, block, lds, st, small, bg, dw, dbias, B, H, W, Cb, big_is_output, ppb); break;
-    case 2: hipLaunchKernelGGL(edge_wgrad_kernel<2>, grid, block, lds, st, small, bg, dw, dbias, B, H, W, Cb, big_is_output, ppb); break;
-    case 3: hipLaunchKernelGGL(edge_wgrad_kernel<3>, grid, block, lds, st, small, bg, dw, dbias, B, H, W, Cb, big_is_output, ppb); break;
-    default: hipLaunchKernelGGL(edge_wgrad_kernel<4>, grid, block, lds, st, small, bg, dw, dbias, B, H, W, Cb, big_is_output, ppb); break;
-  }
-  DM_CHECK_LAUNCH();
-  return DM_OK;
+  const int ndw = Cs * 9 * Cb;
+  DmOrderedSum a = {ws, n, nblocks, n, ndw, n, dw, dbias, nullptr, nullptr};
+  return dm_launch_ordered_sum(a, st);
 }

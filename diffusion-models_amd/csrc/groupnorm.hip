@@ -10,7 +10,9 @@
 //                hundred flops) and stream y = act(ka[c] * x + kb[c])
 //   backward  1. per-(sample, channel) sums of du, du * xhat (and xhat), same decomposition as forward 1
 //             2. group sums from the workspace, then dx streamed; the first pixel-chunk of each sample also emits
-//                the parameter-side gradients (dgamma/dbeta atomics, dscale_shift, dpre_add)
+//                the per-sample parameter-side terms (dscale_shift, dpre_add, and the sample's contribution to
+//                dgamma/dbeta/upstream bias into a [B][3][C] buffer that dm_groupnorm_param_grads sums over the
+//                batch in a fixed order - no float atomics, so the gradients are bitwise reproducible)
 // The second sweep of each pair re-reads a tensor that was just read, which the 256 MiB Infinity Cache serves.
 // The workspace is pure scratch (written before it is read in every call), so one buffer serves every call.
 // The channel axis may be the concatenation of two tensors (x1 | x2).
@@ -37,11 +39,10 @@ struct GnArgs {
   bf16_t* dx2;
   float* mean;
   float* rstd;
-  float* dgamma;
-  float* dbeta;
   float* dss;
   float* dpre;
-  float* dup;   // bias gradient of the convolution that produced x (sum of dx over samples and pixels), or null
+  float* pp;    // per-sample parameter-gradient terms [B][3][C]: dbeta, dgamma, sum of dx over pixels (when want_dup)
+  int want_dup; // the third term (bias gradient of the convolution that produced x) is asked for
   float* ws;
   int B, HW, C1, C2, C, G, cg, act, pch;
   float eps;
@@ -281,18 +282,19 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(GnArgs a) {
     for (int c = threadIdx.x; c < a.C; c += NT) {
       const float av = wa[c], bv = wb[c];
       const float sc = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + c] : 1.f;
-      atomicAdd(a.dbeta + c, sc * av);
-      atomicAdd(a.dgamma + c, sc * bv);
+      float* pp = a.pp + (size_t)b * 3 * a.C;
+      pp[c] = sc * av;
+      pp[a.C + c] = sc * bv;
       if (a.dss) {
         a.dss[(size_t)b * 2 * a.C + c] = a.gamma[c] * bv + a.beta[c] * av;
         a.dss[(size_t)b * 2 * a.C + a.C + c] = av;
       }
-      if (a.dpre || a.dup) {
+      if (a.dpre || a.want_dup) {
         const int g = c / a.cg;
         // sum over pixels of dx = r * (k * a_c - HW * A_g - B_g * sum xhat_c)
         const float dxsum = s_xa[c] * (sc * a.gamma[c] * av - (float)a.HW * s_A[g] - s_B[g] * wx[c]);
         if (a.dpre) a.dpre[(size_t)b * a.C + c] = dxsum;
-        if (a.dup) atomicAdd(a.dup + c, dxsum);
+        if (a.want_dup) pp[2 * a.C + c] = dxsum;
       }
     }
   }
@@ -553,18 +555,19 @@ __global__ __launch_bounds__(FS_MAXT) void gn_bwd_fused_kernel(GnArgs a) {
     if (cj < a.C) {
       const float av = sums[cc], bv = sums[64 + cc], xs = sums[128 + cc];
       const float sc = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + cj] : 1.f;
-      atomicAdd(a.dbeta + cj, sc * av);
-      atomicAdd(a.dgamma + cj, sc * bv);
+      float* pp = a.pp + (size_t)b * 3 * a.C;
+      pp[cj] = sc * av;
+      pp[a.C + cj] = sc * bv;
       if (a.dss) {
         a.dss[(size_t)b * 2 * a.C + cj] = a.gamma[cj] * bv + a.beta[cj] * av;
         a.dss[(size_t)b * 2 * a.C + a.C + cj] = av;
       }
-      if (a.dpre || a.dup) {
+      if (a.dpre || a.want_dup) {
         const int gl = cc / a.cg, g = cj / a.cg;
         const float r = a.rstd[(size_t)b * a.G + g];
         const float dxsum = r * (sc * a.gamma[cj] * av - (float)a.HW * s_A[gl] - s_B[gl] * xs);
         if (a.dpre) a.dpre[(size_t)b * a.C + cj] = dxsum;
-        if (a.dup) atomicAdd(a.dup + cj, dxsum);
+        if (a.want_dup) pp[2 * a.C + cj] = dxsum;
       }
     }
   }
@@ -671,11 +674,11 @@ extern "C" int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const v
 extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma,
                                     const float* beta, const float* scale_shift, const float* pre_add,
                                     const float* mean, const float* rstd, const void* dy, const void* dextra,
-                                    void* dx1, void* dx2, float* dgamma, float* dbeta, float* dscale_shift,
-                                    float* dpre_add, float* dupstream_bias, float* ws, void* stream) {
+                                    void* dx1, void* dx2, float* dscale_shift, float* dpre_add, float* param_partials,
+                                    int want_upstream_bias, float* ws, void* stream) {
   int rc = check_desc(d, "dm_groupnorm_act_bwd");
   if (rc) return rc;
-  DM_REQUIRE(x1 && gamma && beta && mean && rstd && dy && dx1 && dgamma && dbeta && ws, DM_ERR_ARG,
+  DM_REQUIRE(x1 && gamma && beta && mean && rstd && dy && dx1 && param_partials && ws, DM_ERR_ARG,
              "dm_groupnorm_act_bwd: null argument");
   DM_REQUIRE((d->C2 == 0) == (x2 == nullptr) && (d->C2 == 0) == (dx2 == nullptr), DM_ERR_ARG, "dm_groupnorm_act_bwd: x2/dx2 and C2 disagree");
   DM_REQUIRE((d->has_ss != 0) == (scale_shift != nullptr) && (d->has_ss != 0) == (dscale_shift != nullptr), DM_ERR_ARG,
@@ -688,9 +691,9 @@ extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const v
   a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.pre = pre_add;
   a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
   a.dy = (const bf16_t*)dy; a.dextra = (const bf16_t*)dextra;
-  a.dx1 = (bf16_t*)dx1; a.dx2 = (bf16_t*)dx2; a.dgamma = dgamma; a.dbeta = dbeta;
-  DM_REQUIRE(!(dupstream_bias && dextra), DM_ERR_ARG, "dm_groupnorm_act_bwd: dupstream_bias excludes dextra");
-  a.dss = dscale_shift; a.dpre = dpre_add; a.dup = dupstream_bias; a.ws = ws;
+  a.dx1 = (bf16_t*)dx1; a.dx2 = (bf16_t*)dx2;
+  DM_REQUIRE(!(want_upstream_bias && dextra), DM_ERR_ARG, "dm_groupnorm_act_bwd: the upstream bias gradient excludes dextra");
+  a.dss = dscale_shift; a.dpre = dpre_add; a.pp = param_partials; a.want_dup = want_upstream_bias; a.ws = ws;
   fill(a, d);
   hipStream_t st = (hipStream_t)stream;
   if (fused_ok(a, true)) {
@@ -704,4 +707,14 @@ extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const v
   hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, dim3(NT), 0, st, a);
   DM_CHECK_LAUNCH();
   return DM_OK;
+}
+
+extern "C" int dm_groupnorm_param_grads(const dm_gn_desc* d, const float* param_partials, float* dgamma, float* dbeta,
+                                        float* dupstream_bias, void* stream) {
+  int rc = check_desc(d, "dm_groupnorm_param_grads");
+  if (rc) return rc;
+  DM_REQUIRE(param_partials && dgamma && dbeta, DM_ERR_ARG, "dm_groupnorm_param_grads: null argument");
+  const int C = d->C1 + d->C2;
+  DmOrderedSum a = {param_partials, 3L * C, d->B, dupstream_bias ? 3 * C : 2 * C, C, 2 * C, dbeta, dgamma, dupstream_bias, nullptr};
+  return dm_launch_ordered_sum(a, (hipStream_t)stream);
 }

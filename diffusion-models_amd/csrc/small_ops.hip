@@ -327,14 +327,16 @@ __global__ void class_embed_add_kernel(float* __restrict__ emb, const float* __r
   const int b = i / E, e = i - b * E;
   emb[i] += table[(size_t)class_index(cls, mask, uncond, b) * E + e];
 }
+// one thread per (table row, feature): the samples that map to the row are added in batch order
 __global__ void class_embed_bwd_kernel(const float* __restrict__ demb, float* __restrict__ dtable,
                                        const int64_t* __restrict__ cls, const float* __restrict__ mask, int uncond, int B,
                                        int E) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * E) return;
-  const int b = i / E, e = i - b * E;
-  const int idx = class_index(cls, mask, uncond, b);
-  if (idx != uncond) atomicAdd(dtable + (size_t)idx * E + e, demb[i]);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+  if (e >= E || row == uncond) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    if (class_index(cls, mask, uncond, b) == row) s += demb[(size_t)b * E + e];
+  dtable[(size_t)row * E + e] += s;
 }
 
 // ---- 2x resampling, NHWC bf16, one thread per 8 channels of one OUTPUT pixel
@@ -401,36 +403,74 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, long s_co, long 
   if (wd) wd[((long)ci * T + tap) * Cout + co] = v;
 }
 
-// ---- column sums
-__global__ __launch_bounds__(NT) void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ out,
-                                                         float* __restrict__ out2, long M, int C, int rows_per_block) {
-  // per-thread partial sums over this block's rows, combined across the block in LDS: one atomic per column per
-  // block (many blocks adding to the same few addresses is what makes naive column sums slow)
-  __shared__ float red[NT * 8];
-  const int VP = C >> 3, PL = NT / VP;
-  const int v = threadIdx.x % VP, pl = threadIdx.x / VP;
-  const long m0 = (long)blockIdx.x * rows_per_block;
+// ---- column sums: per-(row chunk, 64-column slab) partial sums with plain stores, then the ordered sum
+// One workgroup = 64 columns (8 vectors of 8) x 32 row lanes over rows [blockIdx.y * rpb, +rpb).
+__global__ __launch_bounds__(NT) void colsum_part_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, long M,
+                                                         int C, int rows_per_block) {
+  __shared__ float red[32][65];
+  const int v = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64, c = c0 + 8 * v;
+  const long m0 = (long)blockIdx.y * rows_per_block;
   const long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (pl < PL) {
-    for (long m = m0 + pl; m < m1; m += PL) {
-      float f[8];
-      dm_unpack8(*(const bf16x8_t*)(x + m * C + 8 * v), f);
+  if (c < C) {
+    long m = m0 + pl;
+    for (; m + 96 < m1; m += 128) {
+      const bf16x8_t r0 = *(const bf16x8_t*)(x + m * C + c), r1 = *(const bf16x8_t*)(x + (m + 32) * C + c);
+      const bf16x8_t r2 = *(const bf16x8_t*)(x + (m + 64) * C + c), r3 = *(const bf16x8_t*)(x + (m + 96) * C + c);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+      for (int j = 0; j < 8; ++j) acc[j] += ((float)r0[j] + (float)r1[j]) + ((float)r2[j] + (float)r3[j]);
+    }
+    for (; m < m1; m += 32) {
+      const bf16x8_t r0 = *(const bf16x8_t*)(x + m * C + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (float)r0[j];
     }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[j];
+  for (int j = 0; j < 8; ++j) red[pl][8 * v + j] = acc[j];
   __syncthreads();
-  for (int col = threadIdx.x; col < C; col += NT) {
-    const int vv = col >> 3, j = col & 7;
-    float sum = 0.f;
-    for (int q = 0; q < PL; ++q) sum += red[(q * VP + vv) * 8 + j];
-    atomicAdd(out + col, sum);
-    if (out2) atomicAdd(out2 + col, sum);
+  if (threadIdx.x < 64 && c0 + threadIdx.x < C) {
+    float t = 0.f;
+    for (int q = 0; q < 32; ++q) t += red[q][threadIdx.x];
+    part[(size_t)blockIdx.y * C + c0 + threadIdx.x] = t;
   }
 }
+
+// ---- ordered sum of partial vectors (see DmOrderedSum): one workgroup = 64 elements x 16 waves; wave w adds the
+// partials w, w + 16, ... in order, the 16 run sums are then added in wave order
+constexpr int OS_WAVES = 16;
+__global__ __launch_bounds__(64 * OS_WAVES) void ordered_sum_kernel(const DmOrderedSum a) {
+  __shared__ float red[OS_WAVES][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (e < a.n) {
+    const float* p = a.part + e;
+    int q = w;
+    for (; q + 3 * OS_WAVES < a.nparts; q += 4 * OS_WAVES) {
+      const float v0 = p[(size_t)q * a.stride], v1 = p[(size_t)(q + OS_WAVES) * a.stride];
+      const float v2 = p[(size_t)(q + 2 * OS_WAVES) * a.stride], v3 = p[(size_t)(q + 3 * OS_WAVES) * a.stride];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; q < a.nparts; q += OS_WAVES) s += p[(size_t)q * a.stride];
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w || e >= a.n) return;
+  float t = red[0][lane];
+#pragma unroll
+  for (int g = 1; g < OS_WAVES; ++g) t += red[g][lane];
+  if (e < a.s1) {
+    if (a.out0) a.out0[e] += t;
+    if (a.dual0) a.dual0[e] += t;
+  } else if (e < a.s2) {
+    if (a.out1) a.out1[e - a.s1] += t;
+  } else if (a.out2) {
+    a.out2[e - a.s2] += t;
+  }
+}
+
 __global__ void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -591,10 +631,10 @@ extern "C" int dm_class_embed_add(float* emb, const float* table, const int64_t*
 }
 
 extern "C" int dm_class_embed_bwd(const float* demb, float* dtable, const int64_t* cls, const float* mask, int uncond_idx,
-                                  int B, int E, void* stream) {
-  DM_REQUIRE(demb && dtable && B > 0 && E > 0, DM_ERR_ARG, "dm_class_embed_bwd: bad argument");
+                                  int n_rows, int B, int E, void* stream) {
+  DM_REQUIRE(demb && dtable && B > 0 && E > 0 && n_rows > 0 && n_rows <= 65535, DM_ERR_ARG, "dm_class_embed_bwd: bad argument");
   if (!cls) return DM_OK;  // every row maps to the padding index: no gradient
-  hipLaunchKernelGGL(class_embed_bwd_kernel, dim3(dm_cdiv((long)B * E, NT)), dim3(NT), 0, (hipStream_t)stream, demb, dtable, cls, mask, uncond_idx, B, E);
+  hipLaunchKernelGGL(class_embed_bwd_kernel, dim3(dm_cdiv(E, NT), n_rows), dim3(NT), 0, (hipStream_t)stream, demb, dtable, cls, mask, uncond_idx, B, E);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
@@ -660,23 +700,45 @@ extern "C" int dm_transpose_conv_weights(const void* src, void* dst, const dm_wt
   return DM_OK;
 }
 
-static int colsum_bf16(const void* x, float* out, float* out2, long M, int C, void* stream) {
-  DM_REQUIRE(x && out && M > 0 && C > 0, DM_ERR_ARG, "dm_colsum_bf16: bad argument");
-  DM_REQUIRE(C % 8 == 0 && C / 8 <= NT, DM_ERR_SHAPE, "dm_colsum_bf16: C=%d must be a multiple of 8 and <= %d", C, NT * 8);
-  int rpb = 64;
-  // every workgroup ends with one float atomic per column into the same C addresses: beyond ~64 adders the
-  // contention costs more than the extra workgroups bring (measured inside the training step: 64 beats 32, 128, 256)
-  while (dm_cdiv(M, rpb) > 64) rpb *= 2;
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(dm_cdiv(M, rpb)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, out, out2, M, C, rpb);
+int dm_launch_ordered_sum(const DmOrderedSum& a, hipStream_t st) {
+  DM_REQUIRE(a.part && a.nparts > 0 && a.n > 0 && a.s1 >= 0 && a.s1 <= a.s2 && a.s2 <= a.n, DM_ERR_ARG, "ordered sum: bad argument");
+  hipLaunchKernelGGL(ordered_sum_kernel, dim3(dm_cdiv(a.n, 64)), dim3(64 * OS_WAVES), 0, st, a);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
-extern "C" int dm_colsum_bf16(const void* x, float* out, long M, int C, void* stream) {
-  return colsum_bf16(x, out, nullptr, M, C, stream);
+
+// rows per workgroup of the partial-sum kernel: about 1024 workgroups in all, at least 128 rows each
+static int colsum_rows_per_block(long M, int C) {
+  const int nslab = dm_cdiv(C, 64);
+  long chunks = 1024 / nslab > 0 ? 1024 / nslab : 1;
+  long rpb = (M + chunks - 1) / chunks;
+  rpb = (rpb + 127) / 128 * 128;
+  return (int)rpb;
 }
-extern "C" int dm_colsum_bf16_dual(const void* x, float* out, float* out2, long M, int C, void* stream) {
+
+extern "C" long dm_colsum_ws_floats(long M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  return (long)dm_cdiv(M, colsum_rows_per_block(M, C)) * C;
+}
+
+static int colsum_bf16(const void* x, float* out, float* out2, long M, int C, float* ws, void* stream) {
+  DM_REQUIRE(x && out && ws && M > 0 && C > 0, DM_ERR_ARG, "dm_colsum_bf16: bad argument");
+  DM_REQUIRE(C % 8 == 0, DM_ERR_SHAPE, "dm_colsum_bf16: C=%d must be a multiple of 8", C);
+  DM_REQUIRE((uintptr_t)x % 16 == 0, DM_ERR_ARG, "dm_colsum_bf16: misaligned tensor");
+  const int rpb = colsum_rows_per_block(M, C), chunks = dm_cdiv(M, rpb);
+  DM_REQUIRE(chunks <= 65535, DM_ERR_UNSUPPORTED, "dm_colsum_bf16: %ld rows are too many", M);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_part_kernel, dim3(dm_cdiv(C, 64), chunks), dim3(NT), 0, st, (const bf16_t*)x, ws, M, C, rpb);
+  DM_CHECK_LAUNCH();
+  DmOrderedSum a = {ws, C, chunks, C, C, C, out, nullptr, nullptr, out2};
+  return dm_launch_ordered_sum(a, st);
+}
+extern "C" int dm_colsum_bf16(const void* x, float* out, long M, int C, float* ws, void* stream) {
+  return colsum_bf16(x, out, nullptr, M, C, ws, stream);
+}
+extern "C" int dm_colsum_bf16_dual(const void* x, float* out, float* out2, long M, int C, float* ws, void* stream) {
   DM_REQUIRE(out2, DM_ERR_ARG, "dm_colsum_bf16_dual: null second output");
-  return colsum_bf16(x, out, out2, M, C, stream);
+  return colsum_bf16(x, out, out2, M, C, ws, stream);
 }
 extern "C" int dm_colsum_f32(const float* x, float* out, int R, int C, void* stream) {
   DM_REQUIRE(x && out && R > 0 && C > 0, DM_ERR_ARG, "dm_colsum_f32: bad argument");

@@ -45,21 +45,23 @@ _SIGNATURES = {
     "dm_abi_version": (c_int, []),
     "dm_config_set": (c_int, [ctypes.c_char_p, c_int]),
     "dm_conv2d_igemm": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P]),
-    "dm_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "dm_conv2d_wgrad_ws_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
-    "dm_conv2d_wgrad_ws": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, ctypes.c_size_t, P]),
+    "dm_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, ctypes.c_size_t, P]),
     "dm_pack_conv_weight": (c_int, [P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, P, P]),
     "dm_transpose_conv_weights": (c_int, [P, P, P, c_int, c_int, P]),
-    "dm_colsum_bf16": (c_int, [P, P, c_long, c_int, P]),
-    "dm_colsum_bf16_dual": (c_int, [P, P, P, c_long, c_int, P]),
+    "dm_colsum_ws_floats": (c_long, [c_long, c_int]),
+    "dm_colsum_bf16": (c_int, [P, P, c_long, c_int, P, P]),
+    "dm_colsum_bf16_dual": (c_int, [P, P, P, c_long, c_int, P, P]),
     "dm_colsum_f32": (c_int, [P, P, c_int, c_int, P]),
     "dm_in_conv_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dm_out_conv_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dm_out_conv_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "dm_edge_conv_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dm_edge_conv_wgrad_ws_floats": (c_long, [c_int] * 6),
+    "dm_edge_conv_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "dm_groupnorm_ws_floats": (c_long, [ctypes.POINTER(GnDesc)]),
     "dm_groupnorm_act_fwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 11),
-    "dm_groupnorm_act_bwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 19),
+    "dm_groupnorm_act_bwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 15 + [c_int, P, P]),
+    "dm_groupnorm_param_grads": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 5),
     "dm_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "dm_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "dm_timestep_embed": (c_int, [P, P, P, c_int, c_int, P]),
@@ -69,7 +71,7 @@ _SIGNATURES = {
     "dm_linear_group_bwd_ws_floats": (c_long, [P, c_int, c_int, c_int]),
     "dm_linear_group_bwd": (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, P]),
     "dm_class_embed_add": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
-    "dm_class_embed_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "dm_class_embed_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dm_upsample2x_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "dm_upsample2x_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "dm_avgpool2x_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -108,17 +108,30 @@ def f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
 
 
-_GN_WS = {}
+def _scratch(device, floats, stream=None):
+    """Scratch for one kernel call, from torch's caching allocator: under HIP-graph capture it comes from the
+    graph's private pool, so a captured pointer can never be handed to another tensor while the graph lives (a
+    grow-on-demand buffer shared by all calls could). `stream`: the side stream that will run the kernel."""
+    if stream is None:
+        return torch.empty(max(int(floats), 1), dtype=torch.float32, device=device)
+    with torch.cuda.stream(stream):
+        return torch.empty(max(int(floats), 1), dtype=torch.float32, device=device)
 
 
-def _gn_workspace(device, floats):
-    """The per-device GroupNorm workspace (scratch that every call writes before reading), shared by all calls on
-    the device's stream."""
-    ws = _GN_WS.get(device)
-    if ws is None or ws.numel() < floats:
-        ws = torch.empty(max(floats, 1 << 20), dtype=torch.float32, device=device)
-        _GN_WS[device] = ws
-    return ws
+def _param_stream(tensors, enable=True):
+    """(raw stream, torch stream or None) for a kernel that only produces parameter gradients: the next side stream
+    when the caller turned that mode on (it then waits for the current stream, and `tensors` are kept alive for
+    it), else the current stream."""
+    if not (SIDE_WGRAD and enable):
+        return _stream(), None
+    global _SIDE_NEXT
+    side = side_stream(tensors[0].device, _SIDE_NEXT % SIDE_WGRAD)
+    _SIDE_NEXT += 1
+    side.wait_stream(torch.cuda.current_stream())
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    return side.cuda_stream, side
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -210,17 +223,8 @@ class _ConvFn(Function):
         wsink = _grad_sink(wparam, ohwi=True) if ctx.needs_input_grad[2] else None
         want_db = has_bias and ctx.needs_input_grad[3]
         bsink = _grad_sink(bparam) if want_db else None
-        on_side = SIDE_WGRAD and (wsink is not None or not ctx.needs_input_grad[2]) and (bsink is not None or not want_db)
-        st_w, stream_w = st, torch.cuda.current_stream()
-        if on_side:
-            global _SIDE_NEXT
-            side = side_stream(dy.device, _SIDE_NEXT % SIDE_WGRAD)
-            _SIDE_NEXT += 1
-            side.wait_stream(torch.cuda.current_stream())  # dy (and the saved inputs) are complete
-            st_w, stream_w = side.cuda_stream, side
-            for t in (dy, x1, x2):
-                if t is not None:
-                    t.record_stream(side)
+        on_side = (wsink is not None or not ctx.needs_input_grad[2]) and (bsink is not None or not want_db)
+        st_w, stream_w = _param_stream((dy, x1, x2), on_side)   # dy (and the saved inputs) are complete
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             _, w_dgrad = pack.get(weight)
             dxf = empty_nhwc(B, Cin, Hi, Wi, dy.device)
@@ -238,15 +242,12 @@ class _ConvFn(Function):
         if ctx.needs_input_grad[2]:
             dwf = wsink if wsink is not None else torch.zeros((Cout, KH, KW, Cin), dtype=torch.float32, device=dy.device)
             d = _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, 0, Ho, Wo)
-            # split-K partial tiles go through a scratch workspace where the layer has that path (no float atomics,
-            # order-independent sums); allocated on the stream that runs the kernel
+            # split-K partial tiles go through a scratch workspace (no float atomics, order-independent sums),
+            # allocated on the stream that runs the kernel
             ws_bytes = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(d))
-            ws = None
-            if ws_bytes:
-                with torch.cuda.stream(stream_w):
-                    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
-            check(lib.dm_conv2d_wgrad_ws(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(),
-                                         _p(ws), ws_bytes, st_w))
+            ws = _scratch(dy.device, (ws_bytes + 3) // 4, stream_w)
+            check(lib.dm_conv2d_wgrad(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(),
+                                      ws.data_ptr(), ws.numel() * 4, st_w))
             if wsink is not None:
                 _grad_done(wparam)
             else:
@@ -257,15 +258,20 @@ class _ConvFn(Function):
             dbf = bsink if bsink is not None else torch.zeros(Cout, dtype=torch.float32, device=dy.device)
             twin = ctx.bias_twin
             tsink = _grad_sink(twin) if (twin is not None and bsink is not None) else None
+            M = B * Ho * Wo
+            cws = _scratch(dy.device, lib.dm_colsum_ws_floats(M, Cout), stream_w)
             if tsink is not None:
                 # the twin's convolution produced the other term of the same sum (and ran with bias_grad=False)
-                check(lib.dm_colsum_bf16_dual(dy.data_ptr(), dbf.data_ptr(), tsink.data_ptr(), B * Ho * Wo, Cout, st_w))
+                check(lib.dm_colsum_bf16_dual(dy.data_ptr(), dbf.data_ptr(), tsink.data_ptr(), M, Cout, cws.data_ptr(), st_w))
                 _grad_done(twin)
             else:
-                check(lib.dm_colsum_bf16(dy.data_ptr(), dbf.data_ptr(), B * Ho * Wo, Cout, st_w))
+                check(lib.dm_colsum_bf16(dy.data_ptr(), dbf.data_ptr(), M, Cout, cws.data_ptr(), st_w))
                 if twin is not None:
-                    g = dbf.detach().clone().to(twin.dtype)
-                    twin.grad = g if twin.grad is None else twin.grad + g
+                    g = dbf.detach().to(twin.dtype)
+                    if twin.grad is None:
+                        twin.grad = g.clone()
+                    else:
+                        twin.grad.add_(g)   # in place: a gradient that is a view of a flat arena stays one
             if bsink is not None:
                 _grad_done(bparam)
             else:
@@ -303,7 +309,7 @@ class _GroupNormActFn(Function):
         mean = torch.empty((B, G), dtype=torch.float32, device=x1.device)
         rstd = torch.empty((B, G), dtype=torch.float32, device=x1.device)
         d = GnDesc(B, H * W, C1, C2, G, eps, int(act), int(ss32 is not None), int(pre32 is not None))
-        ws = _gn_workspace(x1.device, 3 * B * C)
+        ws = _scratch(x1.device, lib.dm_groupnorm_ws_floats(ctypes.byref(d)))
         check(lib.dm_groupnorm_act_fwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
                                        _p(ss32), _p(pre32), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                        ws.data_ptr(), _stream()))
@@ -359,12 +365,17 @@ class _GroupNormActFn(Function):
             dub = ub_sink if ub_sink is not None else torch.zeros(C, dtype=torch.float32, device=dev)
         dss = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if ss32 is not None else None
         dpre = torch.empty((B, C), dtype=torch.float32, device=dev) if pre32 is not None else None
-        st = _stream()
-        ws = _gn_workspace(dev, 3 * B * C)
+        ws = _scratch(dev, lib.dm_groupnorm_ws_floats(ctypes.byref(d)))
+        partials = torch.empty((B, 3, C), dtype=torch.float32, device=dev)
         check(lib.dm_groupnorm_act_bwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
                                        _p(ss32), _p(pre32), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(),
-                                       _p(dextra), dx1.data_ptr(), _p(dx2), dg.data_ptr(), db_.data_ptr(), _p(dss),
-                                       _p(dpre), _p(dub), ws.data_ptr(), st))
+                                       _p(dextra), dx1.data_ptr(), _p(dx2), _p(dss), _p(dpre), partials.data_ptr(),
+                                       int(dub is not None), ws.data_ptr(), _stream()))
+        # the batch sums of the per-sample terms feed nothing but the optimizer: off the critical path when the
+        # gradients go straight to their buffers
+        st_p, _ = _param_stream((partials,), direct and (dub is None or ub_sink is not None))
+        check(lib.dm_groupnorm_param_grads(ctypes.byref(d), partials.data_ptr(), dg.data_ptr(), db_.data_ptr(),
+                                           _p(dub), st_p))
         if ub_sink is not None:
             _grad_done(ub)
             dub = None
@@ -568,8 +579,8 @@ class _ClassEmbedAddFn(Function):
         dtable = None
         if ctx.needs_input_grad[1]:
             dtable = torch.zeros(tshape, dtype=torch.float32, device=dout.device)
-            check(lib.dm_class_embed_bwd(dout.data_ptr(), dtable.data_ptr(), _p(cls64), _p(m32), uncond_idx, B, E,
-                                         _stream()))
+            check(lib.dm_class_embed_bwd(dout.data_ptr(), dtable.data_ptr(), _p(cls64), _p(m32), uncond_idx, tshape[0],
+                                         B, E, _stream()))
         return dout, dtable, None, None, None
 
 
@@ -620,15 +631,10 @@ def _edge_wgrad(small, big, weight, bias, shape, big_is_output, wait_for):
     db = None
     if bias is not None:
         db = bsink if direct else torch.zeros((Cb if big_is_output else Cs,), dtype=torch.float32, device=dev)
-    st = _stream()
-    if direct and SIDE_WGRAD:
-        side = side_stream(dev, 0)
-        side.wait_stream(torch.cuda.current_stream())
-        for t in wait_for:
-            t.record_stream(side)
-        st = side.cuda_stream
+    st, stream_w = _param_stream(wait_for, direct)
+    ws = _scratch(dev, lib.dm_edge_conv_wgrad_ws_floats(B, Cs, H, W, Cb, 1 if big_is_output else 0), stream_w)
     check(lib.dm_edge_conv_wgrad(small.data_ptr(), big.data_ptr(), dw.data_ptr(), _p(db), B, Cs, H, W, Cb,
-                                 1 if big_is_output else 0, st))
+                                 1 if big_is_output else 0, ws.data_ptr(), st))
     if direct:
         _grad_done(weight)
         if bias is not None:

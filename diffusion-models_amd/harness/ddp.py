@@ -39,9 +39,10 @@ class BucketedAllReduce:
                     self.bucket_of[i] = b
                     self.size[b] += 1
                     break
-        # Optional: a callable returning the HIP stream the collectives should be ordered after IN ADDITION to the
-        # current one (the stream the weight-gradient kernels run on); None: the current stream only.
-        self.extra_stream = None
+        # Optional: a callable returning the HIP streams the collectives must be ordered after IN ADDITION to the
+        # current one (every stream parameter-gradient kernels run on); None: the current stream only.
+        self.extra_streams = None
+        self.early = 0   # buckets launched before finish() in the last step (i.e. while backward was running)
         self.begin()
 
     def begin(self):
@@ -61,11 +62,15 @@ class BucketedAllReduce:
 
     def _launch(self, b):
         lo, hi = self.buckets[b]
-        side = self.extra_stream() if self.extra_stream is not None else None
-        if side is not None:
-            # issue from the side stream after making it wait for the main one: the collective is then ordered after
-            # the gradients written on either stream, and the main stream is not held up
+        sides = list(self.extra_streams()) if self.extra_streams is not None else []
+        if sides:
+            # issue from the first side stream after making it wait for the main one and for the other side streams:
+            # the collective is then ordered after the gradients written on any of them, and the main stream is not
+            # held up
+            side = sides[0]
             side.wait_stream(torch.cuda.current_stream())
+            for other in sides[1:]:
+                side.wait_stream(other)
             with torch.cuda.stream(side):
                 h = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
@@ -78,6 +83,7 @@ class BucketedAllReduce:
         and turns the sums into means."""
         if self.world == 1:
             return
+        self.early = len(self.launched)
         for b in range(len(self.buckets)):
             if b not in self.launched:
                 self._launch(b)

@@ -84,7 +84,10 @@ class TrainStep:
         if self.side_wgrad is None:
             self.side_wgrad = 1
         if self.world > 1 and self.side_wgrad and dev.type == "cuda":
-            self.reducer.extra_stream = lambda: ops.side_stream(dev, 0)
+            # every side stream that may carry parameter-gradient kernels (side_wgrad can be raised after
+            # construction; streams that were never created carry nothing)
+            self.reducer.extra_streams = lambda: [ops.side_stream(dev, 0)] + [
+                s for s in ops.side_streams(dev) if s is not ops.side_stream(dev, 0)]
         self._in_backward = False
         self._param_index = {id(p): i for i, (_, p) in enumerate(self.arena.params)}
         if self.world > 1:

@@ -63,20 +63,16 @@ typedef struct dm_conv_desc {
 int dm_conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
                     const void* res, void* y, void* stream);
 
-/* dw[n][tap][c] += sum_m dy[m][n] * X(m,tap)[c]; dw fp32 [Cout][KH*KW][C1+C2], ACCUMULATES (atomics) */
-int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, void* stream);
-
-/* The same with a caller-provided scratch workspace (16-byte aligned, at least dm_conv2d_wgrad_ws_bytes(d) bytes,
- * contents irrelevant on entry and on return; null / 0 selects the call above). Where the layer has a slab path
- * (3x3, stride 1, pad 1, output width 8..64 dividing 64; or any layer whose input channels per source and output
- * channels are multiples of 128), the split-K partial tiles go to the workspace with plain
- * stores and a second kernel adds their sum to dw: no float atomics, and a result that does not depend on the
- * order in which workgroups finish. dm_conv2d_wgrad_ws_bytes returns 0 for layers without that path.
- * Same operator as above: the weight gradient autograd computes for nn.Conv2d of modeling/blocks.py:26,28,110
- * inside loss.backward() (train.py:440). */
+/* dw[n][tap][c] += sum_m dy[m][n] * X(m,tap)[c]; dw fp32 [Cout][KH*KW][C1+C2], ACCUMULATES.
+ * ws: caller-provided scratch (16-byte aligned, at least dm_conv2d_wgrad_ws_bytes(d) bytes, contents irrelevant on
+ * entry and on return). The split-K partial tiles go to the workspace with plain stores and a second kernel adds
+ * their sum to dw in slice order: no float atomics, so the result does not depend on the order in which workgroups
+ * finish (bitwise reproducible).
+ * The weight gradient autograd computes for nn.Conv2d of modeling/blocks.py:26,28,45,89,110 inside loss.backward()
+ * (train.py:440). */
 size_t dm_conv2d_wgrad_ws_bytes(const dm_conv_desc* d);
-int dm_conv2d_wgrad_ws(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, void* ws,
-                       size_t ws_bytes, void* stream);
+int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, void* ws,
+                    size_t ws_bytes, void* stream);
 
 /* fp32 parameter [Cout][Cin][KH][KW] with arbitrary element strides -> bf16 [Cout][T][Cin] (w_fwd) and
  * bf16 [Cin][T][Cout] (w_dgrad); either output may be null */
@@ -96,11 +92,14 @@ typedef struct dm_wt_item {
 int dm_transpose_conv_weights(const void* src, void* dst, const dm_wt_item* items_dev, int n_items, int n_tiles,
                               void* stream);
 
-/* out[c] += sum_m x[m][c]  (bias gradients; x bf16 [M][C], out fp32) */
-int dm_colsum_bf16(const void* x, float* out, long M, int C, void* stream);
+/* out[c] += sum_m x[m][c]  (bias gradients; x bf16 [M][C], out fp32). ws: scratch of dm_colsum_ws_floats(M, C)
+ * floats; row chunks are summed into it with plain stores and added to out in chunk order (no float atomics).
+ * The bias gradient autograd computes for nn.Conv2d (modeling/blocks.py:26,28,45,89,110). */
+long dm_colsum_ws_floats(long M, int C);
+int dm_colsum_bf16(const void* x, float* out, long M, int C, float* ws, void* stream);
 /* the same sums added into two outputs: a block's conv2 and res_proj (modeling/blocks.py:28,45,74-75) produce the
  * two terms of one sum, so their bias gradients are the same column sums */
-int dm_colsum_bf16_dual(const void* x, float* out, float* out2, long M, int C, void* stream);
+int dm_colsum_bf16_dual(const void* x, float* out, float* out2, long M, int C, float* ws, void* stream);
 /* out[c] += sum_r x[r][c]  (x fp32 [R][C]) */
 int dm_colsum_f32(const float* x, float* out, int R, int C, void* stream);
 
@@ -121,8 +120,11 @@ int dm_out_conv_dgrad(const float* dy, const float* w, void* dh, int B, int Cs, 
  *   big_is_output=1 (in_conv):  dw[cb][cs][kh][kw] += sum big[m][cb] * small[b][cs][h+kh-1][w+kw-1]; dbias[cb] += sum big
  *   big_is_output=0 (out_conv): dw[cs][cb][kh][kw] += sum small[b][cs][h][w] * big[(h+kh-1, w+kw-1)][cb]; dbias[cs] += sum small
  */
+/* ws: scratch of dm_edge_conv_wgrad_ws_floats(...) floats: every workgroup leaves its partial sums there and they are
+ * added to dw / dbias in workgroup order (no float atomics). */
+long dm_edge_conv_wgrad_ws_floats(int B, int Cs, int H, int W, int Cb, int big_is_output);
 int dm_edge_conv_wgrad(const float* small, const void* big, float* dw, float* dbias, int B, int Cs, int H, int W,
-                       int Cb, int big_is_output, void* stream);
+                       int Cb, int big_is_output, float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * GroupNorm (+ per-sample scale/shift or pre-add) (+ SiLU), fused; channel axis may be two sources.
@@ -147,15 +149,20 @@ long dm_groupnorm_ws_floats(const dm_gn_desc* d);
 int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma, const float* beta,
                          const float* scale_shift, const float* pre_add, void* y, float* mean, float* rstd, float* ws,
                          void* stream);
-/* dx1|dx2 bf16 (= GN backward + dextra, dextra optional bf16 [B][HW][C]); dgamma/dbeta fp32 [C] ACCUMULATE
- * (atomics); dscale_shift fp32 [B][2C] and dpre_add fp32 [B][C] are written when present.
- * dupstream_bias (nullable, fp32 [C], ACCUMULATES, excludes dextra): sum of dx over samples and pixels, i.e. the bias
- * gradient of the convolution whose output x is (modeling/blocks.py:51 -> :59); it falls out of the sums this
- * operator forms anyway, so that convolution needs no column-sum pass over dx. */
+/* dx1|dx2 bf16 (= GN backward + dextra, dextra optional bf16 [B][HW][C]); dscale_shift fp32 [B][2C] and dpre_add
+ * fp32 [B][C] are written when present. param_partials (fp32 [B][3][C], written): every sample's contribution to
+ * dbeta ([b][0][c]), dgamma ([b][1][c]) and, when want_upstream_bias (excludes dextra), the sum of dx over the
+ * sample's pixels ([b][2][c]): the bias gradient of the convolution whose output x is (modeling/blocks.py:51 -> :59)
+ * falls out of the sums this operator forms anyway, so that convolution needs no column-sum pass over dx.
+ * dm_groupnorm_param_grads adds the batch sum of those terms, taken in sample order (no float atomics: bitwise
+ * reproducible), to dgamma / dbeta / dupstream_bias (fp32 [C], ACCUMULATE; dupstream_bias nullable). It may run on
+ * another stream than the backward kernel, once that has finished: nothing but the optimizer consumes its results. */
 int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma, const float* beta,
                          const float* scale_shift, const float* pre_add, const float* mean, const float* rstd,
-                         const void* dy, const void* dextra, void* dx1, void* dx2, float* dgamma, float* dbeta,
-                         float* dscale_shift, float* dpre_add, float* dupstream_bias, float* ws, void* stream);
+                         const void* dy, const void* dextra, void* dx1, void* dx2, float* dscale_shift,
+                         float* dpre_add, float* param_partials, int want_upstream_bias, float* ws, void* stream);
+int dm_groupnorm_param_grads(const dm_gn_desc* d, const float* param_partials, float* dgamma, float* dbeta,
+                             float* dupstream_bias, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Spatial self-attention core. Replaces F.scaled_dot_product_attention and the view/permute/contiguous
@@ -201,9 +208,10 @@ int dm_linear_group_bwd(const float* x, const dm_linear_item* items, int P, floa
 /* emb[b][:] += table[idx(b)][:], idx(b) = (cls == null || mask[b] != 0) ? uncond_idx : cls[b] */
 int dm_class_embed_add(float* emb, const float* table, const int64_t* cls, const float* mask, int uncond_idx, int B,
                        int E, void* stream);
-/* dtable[idx(b)][:] += demb[b][:] for idx(b) != uncond_idx (the padding row never receives gradient) */
-int dm_class_embed_bwd(const float* demb, float* dtable, const int64_t* cls, const float* mask, int uncond_idx, int B,
-                       int E, void* stream);
+/* dtable[idx(b)][:] += demb[b][:] for idx(b) != uncond_idx (the padding row never receives gradient); dtable has
+ * n_rows rows; the samples of a row are added in batch order */
+int dm_class_embed_bwd(const float* demb, float* dtable, const int64_t* cls, const float* mask, int uncond_idx,
+                       int n_rows, int B, int E, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Resampling without conv (modeling/blocks.py:92 AvgPool2d, :116 F.interpolate nearest) and the 2x2 gather of

@@ -14,7 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order: oracle and host logic, then operator parity, layer/model/sampler/training parity against the
+# reference fixtures, and only then the harness's self-consistency and multi-process tests - under `pytest -x` a
+# failure in a late file cannot hide the parity tests. Unlisted files run after the listed ones, by name.
+_FILE_ORDER = ["test_oracle_golden.py", "test_host_logic.py", "test_gpu_ops.py", "test_gpu_model.py",
+               "test_generate.py", "test_gpu_harness.py", "test_ddp_gloo.py", "test_ddp_gpu.py"]
+
+
 def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        return (_FILE_ORDER.index(name), "") if name in _FILE_ORDER else (len(_FILE_ORDER), name)
+    items.sort(key=rank)   # stable: the order inside a file is kept
     import torch
     if torch.cuda.is_available():
         return

@@ -14,7 +14,7 @@ from tests.parity import PKG, ROOT, TINY_CFG
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, side_wgrad=1):
     for p in (ROOT, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -31,7 +31,7 @@ def _worker(rank, world, port, q):
         model.load_state_dict(det_sd_for(model, 11))
         model = model.to(dev).train()
         sched = get_scheduler("beta", n_steps=1000)
-        step = TrainStep(model, sched, lr=2e-4, clip_grad_norm=1.0, use_ema=False, bucket_mb=1)
+        step = TrainStep(model, sched, lr=2e-4, clip_grad_norm=1.0, use_ema=False, bucket_mb=1, side_wgrad=side_wgrad)
         assert step.world == world and (world == 1 or len(step.reducer.buckets) > 2)
         g = torch.Generator().manual_seed(5)
         B = 8
@@ -43,7 +43,7 @@ def _worker(rank, world, port, q):
         lo, hi = rank * B // world, (rank + 1) * B // world
         before = step.arena.data.clone()
         loss, gnorm = step.step_given_noise(*(v[lo:hi].to(dev) for v in (x, cls, mask, eps, t)))
-        early = len(step.reducer.launched)
+        early = step.reducer.early   # buckets that went out before finish(), i.e. while backward was running
         torch.cuda.synchronize()
         q.put((rank, float(loss), float(gnorm), (step.arena.data - before).cpu().numpy(), early))
     finally:
@@ -51,10 +51,10 @@ def _worker(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def _run(world, port):
+def _run(world, port, side_wgrad=1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, side_wgrad)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
@@ -72,14 +72,17 @@ def _run(world, port):
     return res
 
 
-def test_two_ranks_equal_one_rank_on_the_concatenated_batch():
-    (_, loss1, norm1, delta1, _), = _run(1, 0)
-    two = _run(2, 29617)
+@pytest.mark.parametrize("side_wgrad", [1, 2])
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(side_wgrad):
+    """side_wgrad=2: parameter-gradient kernels rotate over two side streams; every bucket's all-reduce must be
+    ordered after both."""
+    (_, loss1, norm1, delta1, _), = _run(1, 0, side_wgrad)
+    two = _run(2, 29617 + side_wgrad, side_wgrad)
     # the full-batch loss is the mean of the two half-batch losses
     assert abs(0.5 * (two[0][1] + two[1][1]) - loss1) < 1e-3 * abs(loss1)
     for _, _, norm2, delta2, early in two:
         assert abs(norm2 - norm1) < 5e-3 * norm1          # global norm of the AVERAGED gradient, on every rank
         assert early > 0                                   # buckets went out before backward had finished
         num = float((delta2 - delta1).norm()) / float(delta1.norm())
-        assert num < 0.1, num                              # same AdamW update (bf16 kernels, atomics: not bit-equal)
+        assert num < 0.1, num                              # same AdamW update (bf16 kernels, other batch split: not bit-equal)
     assert torch.equal(two[0][3], two[1][3])               # replicas stay identical

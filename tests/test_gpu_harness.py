@@ -1,0 +1,131 @@
+"""GPU: self-consistency of the training/sampling harness (no reference involved): bitwise reproducibility of
+the training step, the phase-split form used for HIP-graph replay on several GPUs, and graph replay beside eager
+calls. Collected after the oracle-parity tests (tests/conftest.py orders the files)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.parity import TINY_CFG, det_sd_for
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _worst_params(a, b, lr):
+    """Per-parameter worst |a - b| / lr between two TrainSteps, largest first (names the tensors that differ)."""
+    rows = []
+    for (n, p), o in zip(a.arena.params, a.arena.offsets):
+        d = float((a.arena.data[o:o + p.numel()] - b.arena.data[o:o + p.numel()]).abs().max()) / lr
+        if d > 0:
+            rows.append((d, n))
+    return sorted(rows, reverse=True)[:8]
+
+
+def _make_step(seed=11, **kw):
+    from diffusion.scheduler import get_scheduler
+    from harness.train_step import TrainStep
+    from modeling import get_model
+    m = get_model("unet", **TINY_CFG)
+    m.load_state_dict(det_sd_for(m, seed))
+    return TrainStep(m.to(dev()).train(), get_scheduler("beta", n_steps=1000), lr=2e-4, clip_grad_norm=1.0,
+                     use_ema=True, **kw)
+
+
+def _batch(B=8):
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(B, 3, 16, 16, generator=g) * 2 - 1).to(dev())
+    cls = torch.randint(0, 10, (B,), generator=g).to(dev())
+    return x, cls
+
+
+def test_training_step_is_bitwise_reproducible():
+    """Two TrainSteps from the same state, same random draws: every gradient reduction runs in a fixed order (no float
+    atomics anywhere in the step), so parameters, EMA and bf16 mirrors agree bit for bit after several steps - with
+    the parameter-gradient kernels on the main stream, on one side stream and rotating over two."""
+    x, cls = _batch()
+    results = []
+    for side in (1, 1, 0, 2):
+        s_ = _make_step(side_wgrad=side)
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(77)
+        losses = [float(s_.step(x, cls)) for _ in range(3)]
+        torch.cuda.synchronize()
+        results.append((s_, losses))
+    a = results[0][0]
+    for b, losses in results[1:]:
+        assert losses == results[0][1], (losses, results[0][1])
+        assert torch.equal(b.arena.data, a.arena.data), _worst_params(a, b, 2e-4)
+        assert torch.equal(b.ema, a.ema) and torch.equal(b.w16, a.w16) and torch.equal(b.w16_t, a.w16_t)
+
+
+def test_step_in_phases_equals_step():
+    """forward_backward -> reduce -> update (the form whose local phases are captured as two HIP graphs on more than
+    one GPU) is the same step as step(): same random draws, bit-identical parameters afterwards, eagerly and replayed."""
+    x, cls = _batch()
+    a, b, c = _make_step(), _make_step(), _make_step()
+    for s_ in (a, b):
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(77)
+        if s_ is a:
+            la = [s_.step(x, cls) for _ in range(2)]
+        else:
+            lb = []
+            for _ in range(2):
+                lb.append(s_.forward_backward(x, cls))
+                s_.reduce()
+                s_.update()
+    torch.cuda.synchronize()
+    assert float(la[0]) == float(lb[0]) and float(la[1]) == float(lb[1])
+    assert torch.equal(b.arena.data, a.arena.data), _worst_params(a, b, 2e-4)
+    assert torch.equal(b.ema, a.ema)
+    # the two phases as graphs, the reduction between them
+    from dm_hip import ops
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    ops.FORCE_REPACK = True
+    try:
+        with torch.cuda.stream(side):
+            c.forward_backward(x, cls); c.reduce(); c.update()
+            torch.cuda.synchronize()
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, stream=side):
+                loss = c.forward_backward(x, cls)
+            c.reduce()
+            with torch.cuda.graph(g2, stream=side):
+                c.update()
+    finally:
+        ops.FORCE_REPACK = False
+    torch.cuda.current_stream().wait_stream(side)
+    before = c.arena.data.clone()
+    for _ in range(3):
+        g1.replay(); c.reduce(); g2.replay()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and float(c.arena.grad.abs().max()) == 0.0
+    assert 0 < float((c.arena.data - before).abs().max()) <= 3 * 2e-4 * 1.05
+    assert torch.equal(c.w16, c.arena.data.to(torch.bfloat16))
+
+
+def test_captured_graph_survives_larger_eager_calls():
+    """Scratch buffers are per call (from the graph's private pool under capture): a forward captured at a small
+    batch must replay correctly after larger eager calls have run (train-then-generate flow)."""
+    from harness.generate import GraphedPredictor
+    from modeling import get_model
+    m = get_model("unet", **TINY_CFG)
+    m.load_state_dict(det_sd_for(m, 11))
+    m = m.to(dev()).eval()
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(4, 3, 16, 16, generator=g).to(dev())
+    t = torch.full((4,), 500, dtype=torch.int64, device=dev())
+    cls = torch.randint(0, 10, (4,), generator=g).to(dev())
+    with torch.no_grad():
+        gp = GraphedPredictor(m.get_pred_fn(cond=cls, guidance_scale=1.0))
+        first = gp(z, t).clone()
+        zb = torch.randn(64, 3, 16, 16, generator=g).to(dev())
+        m.get_pred_fn(cond=torch.randint(0, 10, (64,), generator=g).to(dev()), guidance_scale=2.0)(
+            zb, torch.full((64,), 3, dtype=torch.int64, device=dev()))
+        torch.cuda.synchronize()
+        again = gp(z, t).clone()
+    assert torch.equal(first, again)

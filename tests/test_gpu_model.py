@@ -313,66 +313,6 @@ def test_full_size_training_step_invariants():
     assert torch.equal(step.w16_t[o:o + n].view(ci, taps, co), step.w16[o:o + n].view(co, taps, ci).permute(2, 1, 0))
 
 
-def test_step_in_phases_equals_step():
-    """forward_backward -> reduce -> update (the form whose local phases are captured as two HIP graphs on more than
-    one GPU) is the same step as step(): same random draws, same parameters afterwards, eagerly and replayed."""
-    from diffusion.scheduler import get_scheduler
-    from harness.train_step import TrainStep
-    from modeling import get_model
-    from tests.parity import det_sd_for
-    g = torch.Generator().manual_seed(3)
-    x = (torch.rand(8, 3, 16, 16, generator=g) * 2 - 1).to(dev())
-    cls = torch.randint(0, 10, (8,), generator=g).to(dev())
-
-    def make():
-        m = get_model("unet", **TINY_CFG)
-        m.load_state_dict(det_sd_for(m, 11))
-        return TrainStep(m.to(dev()).train(), get_scheduler("beta", n_steps=1000), lr=2e-4, clip_grad_norm=1.0, use_ema=True)
-
-    a, b, c = make(), make(), make()
-    for s_ in (a, b):
-        torch.manual_seed(77)
-        torch.cuda.manual_seed(77)
-        if s_ is a:
-            la = [s_.step(x, cls) for _ in range(2)]
-        else:
-            lb = []
-            for _ in range(2):
-                lb.append(s_.forward_backward(x, cls))
-                s_.reduce()
-                s_.update()
-    torch.cuda.synchronize()
-    assert float(la[0]) == float(lb[0])                            # same weights, same draws
-    assert abs(float(la[1]) - float(lb[1])) < 1e-5 * float(la[1])  # after one update (float-atomic bias/affine gradients)
-    # parameter-side GroupNorm gradients are float atomics: equal up to summation order
-    assert rel_err(b.arena.data, a.arena.data) < 1e-6 and rel_err(b.ema, a.ema) < 1e-6
-    # the two phases as graphs, the reduction between them
-    from dm_hip import ops
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    ops.FORCE_REPACK = True
-    try:
-        with torch.cuda.stream(side):
-            c.forward_backward(x, cls); c.reduce(); c.update()
-            torch.cuda.synchronize()
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, stream=side):
-                loss = c.forward_backward(x, cls)
-            c.reduce()
-            with torch.cuda.graph(g2, stream=side):
-                c.update()
-    finally:
-        ops.FORCE_REPACK = False
-    torch.cuda.current_stream().wait_stream(side)
-    before = c.arena.data.clone()
-    for _ in range(3):
-        g1.replay(); c.reduce(); g2.replay()
-    torch.cuda.synchronize()
-    assert np.isfinite(float(loss)) and float(c.arena.grad.abs().max()) == 0.0
-    assert 0 < float((c.arena.data - before).abs().max()) <= 3 * 2e-4 * 1.05
-    assert torch.equal(c.w16, c.arena.data.to(torch.bfloat16))
-
-
 def test_loss_curve_1000_steps_vs_reference():
     """1000 training steps of the tiny model on the structured data set of tests/parity.py:curve_batches, same
     batches and noise as the reference run that produced the fixture. bf16 kernels against an fp32 reference: the

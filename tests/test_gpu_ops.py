@@ -109,49 +109,107 @@ def _conv2d_case(B, C1, C2, Cout, H, W, k, stride, ups):
     assert rel_err(resd.grad.float(), resr.grad) < 1e-6
 
 
-@pytest.mark.parametrize("B,C1,C2,Cout,H,W,ups,k", [
-    (64, 128, 0, 128, 32, 32, 0, 3),     # many pixel slices per tile
-    (32, 64, 64, 192, 16, 16, 0, 3),     # two sources, Cout not a multiple of the 128-channel tile
-    (16, 128, 0, 64, 8, 8, 1, 3),        # fused upsample, half-empty output-channel tile
-    (2, 64, 0, 64, 8, 8, 0, 3),          # a single slice
-    (64, 256, 128, 128, 32, 32, 0, 1),   # 1x1 over two sources: the single-tap kernel's slab path (128 x 128 tiles)
-    (8, 128, 0, 256, 16, 16, 0, 1),
+@pytest.mark.parametrize("B,C1,C2,Cout,H,W,ups,k,stride", [
+    (64, 128, 0, 128, 32, 32, 0, 3, 1),     # many pixel slices per tile
+    (32, 64, 64, 192, 16, 16, 0, 3, 1),     # two sources, Cout not a multiple of the 128-channel tile
+    (16, 128, 0, 64, 8, 8, 1, 3, 1),        # fused upsample, half-empty output-channel tile
+    (2, 64, 0, 64, 8, 8, 0, 3, 1),          # a single slice
+    (64, 256, 128, 128, 32, 32, 0, 1, 1),   # 1x1 over two sources: single-tap kernel, 128 x 128 tiles
+    (8, 128, 0, 256, 16, 16, 0, 1, 1),
+    (16, 64, 0, 64, 16, 16, 0, 1, 1),       # 64 x 64 tiles
+    (8, 64, 64, 192, 8, 8, 0, 1, 1),        # 64-wide tiles on both axes, ragged output-channel tile
+    (8, 64, 0, 128, 16, 16, 0, 3, 2),       # stride 2: 128 x 64 tiles
+    (8, 128, 0, 72, 14, 14, 0, 3, 2),       # 64 x 128 tiles, Cout = 72, 7x7 output
+    (4, 64, 0, 64, 28, 28, 0, 3, 1),        # width 28 does not divide 64: single-tap kernel on a 3x3 layer
 ])
-def test_conv2d_wgrad_workspace(B, C1, C2, Cout, H, W, ups, k):
-    """The slab path of the weight gradient (partial tiles to a workspace, summed by a second kernel) against the
-    atomic path on the same inputs; it accumulates into dw like the atomic path, leaves dw alone outside the
-    tensor, and gives bit-identical results from run to run (sums in slice order)."""
+def test_conv2d_wgrad_workspace(B, C1, C2, Cout, H, W, ups, k, stride):
+    """The weight gradient (split-K partial tiles to a workspace, summed in slice order by a second kernel) against
+    torch's fp32 conv weight gradient on the same bf16-rounded operands; it accumulates into dw, leaves memory
+    behind dw alone, does not depend on the workspace's contents and gives bit-identical results from run to run."""
     import ctypes
     from dm_hip import ConvDesc, check, lib
     d_ = dev()
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cout)
     bf = torch.bfloat16
-    Ho, Wo = H << ups, W << ups
+    pad = (k - 1) // 2
+    Hi, Wi = H << ups, W << ups
+    Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
     Cin = C1 + C2
-    x1 = torch.randn(B, H, W, C1, generator=g).to(bf).to(d_)
-    x2 = torch.randn(B, H, W, C2, generator=g).to(bf).to(d_) if C2 else None
-    dy = torch.randn(B, Ho, Wo, Cout, generator=g).to(bf).to(d_)
-    desc = ConvDesc(B, H, W, C1, C2, Cout, k, k, 1, (k - 1) // 2, ups, 0, Ho, Wo)
+    x1c = torch.randn(B, H, W, C1, generator=g).to(bf)
+    x2c = torch.randn(B, H, W, C2, generator=g).to(bf) if C2 else None
+    dyc = torch.randn(B, Ho, Wo, Cout, generator=g).to(bf)
+    x1, x2, dy = x1c.to(d_), (x2c.to(d_) if C2 else None), dyc.to(d_)
+    desc = ConvDesc(B, H, W, C1, C2, Cout, k, k, stride, pad, ups, 0, Ho, Wo)
     p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     nbytes = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(desc))
-    assert nbytes > 0 and nbytes % ((3 * 128 * 64 if k == 3 else 128 * 128) * 4) == 0
+    assert nbytes > 0 and nbytes % (64 * 64 * 4) == 0
+    # fp32 reference on the CPU: dw[co][kh][kw][ci]
+    xin = (x1c if x2c is None else torch.cat([x1c, x2c], -1)).float().permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    wz = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+    F.conv2d(xin, wz, None, stride=stride, padding=pad).backward(dyc.float().permute(0, 3, 1, 2))
+    want = wz.grad.permute(0, 2, 3, 1).reshape(-1)
     base = torch.randn(Cout * k * k * Cin + 64, generator=g).to(d_)       # dw accumulates; 64 guard floats behind it
-    ref = base.clone()
-    check(lib.dm_conv2d_wgrad(ctypes.byref(desc), p(x1), p(x2), p(dy), ref.data_ptr(), st))
     outs = []
-    for fill in (0.0, float("nan")):                                   # the workspace's contents do not matter
+    for fill in (0.0, float("nan"), 1.0):                                  # the workspace's contents do not matter
         ws = torch.full((nbytes // 4,), fill, device=d_)
         out = base.clone()
-        check(lib.dm_conv2d_wgrad_ws(ctypes.byref(desc), p(x1), p(x2), p(dy), out.data_ptr(), ws.data_ptr(), nbytes, st))
+        check(lib.dm_conv2d_wgrad(ctypes.byref(desc), p(x1), p(x2), p(dy), out.data_ptr(), ws.data_ptr(), nbytes, st))
         outs.append(out)
     torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert torch.equal(outs[0][-64:], base[-64:])
-    assert rel_err(outs[0][:-64] - base[:-64], ref[:-64] - base[:-64]) < 1e-5   # fp32 sums in a different order
+    assert rel_err(outs[0][:-64] - base[:-64], want) < 2e-5    # exact bf16 products, fp32 sums in another order
     # too small a workspace is an error, not a silent fallback
     small = torch.empty(16, device=d_)
-    assert lib.dm_conv2d_wgrad_ws(ctypes.byref(desc), p(x1), p(x2), p(dy), out.data_ptr(), small.data_ptr(), 64, st) != 0
+    assert lib.dm_conv2d_wgrad(ctypes.byref(desc), p(x1), p(x2), p(dy), out.data_ptr(), small.data_ptr(), 64, st) != 0
+
+
+def test_parameter_gradient_kernels_are_bitwise_reproducible():
+    """Every parameter-gradient reduction (GroupNorm affine and upstream bias, conv bias column sums, edge-conv
+    weights, class table) sums in a fixed order: two runs on the same inputs must agree bit for bit."""
+    from dm_hip import ops
+    d = dev()
+
+    def run():
+        outs = []
+        # GroupNorm, both kernel families (256 and 1024 pixels), with the upstream-bias output
+        for H in (16, 32):
+            x = q(rnd(rs2, 24, 128, H, H)).to(d).requires_grad_(True)
+            ga, be, ub = (rnd(rs2, 128).to(d).requires_grad_(True) for _ in range(3))
+            y = ops.group_norm_act(x, ga, be, 32, 1e-5, True, upstream_bias=ub)
+            y.backward(q(rnd(rs2, *y.shape)).to(d))
+            outs += [ga.grad, be.grad, ub.grad]
+        # conv bias (column sums) and weight
+        x = q(rnd(rs2, 16, 64, 16, 16)).to(d)
+        w, b = rnd(rs2, 64, 64, 3, 3, scale=0.05).to(d).requires_grad_(True), rnd(rs2, 64).to(d).requires_grad_(True)
+        y = ops.conv2d(x, w, b, ops.WeightPack(), pad=1)
+        y.backward(q(rnd(rs2, *y.shape)).to(d))
+        outs += [w.grad, b.grad]
+        # edge convolutions (matrix-core kernel at width 16, VALU kernel at width 7)
+        for Wd in (16, 7):
+            img = rnd(rs2, 8, 3, Wd, Wd).to(d)
+            w1, b1 = rnd(rs2, 64, 3, 3, 3).to(d).requires_grad_(True), rnd(rs2, 64).to(d).requires_grad_(True)
+            h = ops.in_conv(img, w1, b1)
+            w2, b2 = rnd(rs2, 3, 64, 3, 3).to(d).requires_grad_(True), rnd(rs2, 3).to(d).requires_grad_(True)
+            o = ops.out_conv(h, w2, b2)
+            o.backward(rnd(rs2, *o.shape).to(d))
+            outs += [w1.grad, b1.grad, w2.grad, b2.grad]
+        # class table
+        emb, table = rnd(rs2, 64, 32).to(d).requires_grad_(True), rnd(rs2, 11, 32).to(d).requires_grad_(True)
+        cls = T(rs2.randint(0, 10, size=(64,)).astype(np.int64)).to(d)
+        ops.class_embed_add(emb, table, cls, None, 10).backward(rnd(rs2, 64, 32).to(d))
+        outs.append(table.grad)
+        torch.cuda.synchronize()
+        return [o.clone() for o in outs]
+
+    rs2 = np.random.RandomState(78)
+    a = run()
+    rs2 = np.random.RandomState(78)
+    b = run()
+    assert all(torch.equal(u, v) for u, v in zip(a, b)), [i for i, (u, v) in enumerate(zip(a, b)) if not torch.equal(u, v)]
 
 
 GN_CASES = [
