@@ -40,21 +40,11 @@ void dm_set_error(const char* fmt, ...);
 
 static inline int dm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// Ordered sum of per-workgroup partial vectors into accumulating outputs (the library's replacement for float
-// atomics on parameter gradients: the order of the additions is fixed, so results are bitwise reproducible).
-//   s[e] = sum_q part[q * stride + e], q = 0 .. nparts-1 (four interleaved runs, combined in run order), e < n
-//   e in [0, s1): out0[e] += s (and dual0[e] += s when given); [s1, s2): out1[e - s1] += s; [s2, n): out2[e - s2] += s
-// A null output skips its segment.
-struct DmOrderedSum {
-  const float* part;
-  long stride;
-  int nparts, n, s1, s2;
-  float* out0;
-  float* out1;
-  float* out2;
-  float* dual0;
-};
-int dm_launch_ordered_sum(const DmOrderedSum& a, hipStream_t st);
+// Ordered sum of per-workgroup partial vectors into accumulating outputs (dm_sum_item, see the public header): the
+// library's replacement for float atomics on parameter gradients. With `deferred` the item is handed to the caller
+// (who runs it later through dm_ordered_sum_group) instead of being launched.
+typedef dm_sum_item DmOrderedSum;
+int dm_finish_ordered_sum(const DmOrderedSum& a, dm_sum_item* deferred, hipStream_t st);
 
 __device__ __forceinline__ float dm_silu(float v) { return v / (1.0f + __expf(-v)); }
 // d/dv [v * sigmoid(v)] = s * (1 + v * (1 - s))

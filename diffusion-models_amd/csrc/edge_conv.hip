@@ -452,7 +452,7 @@ extern "C" long dm_edge_conv_wgrad_ws_floats(int B, int Cs, int H, int W, int Cb
 }
 
 extern "C" int dm_edge_conv_wgrad(const float* small, const void* big, float* dw, float* dbias, int B, int Cs, int H,
-                                  int W, int Cb, int big_is_output, float* ws, void* stream) {
+                                  int W, int Cb, int big_is_output, float* ws, dm_sum_item* deferred, void* stream) {
   int rc = check_edge("dm_edge_conv_wgrad", B, Cs, H, W, Cb);
   if (rc) return rc;
   DM_REQUIRE(small && big && dw && ws, DM_ERR_ARG, "dm_edge_conv_wgrad: null argument");
@@ -486,5 +486,5 @@ extern "C" int dm_edge_conv_wgrad(const float* small, const void* big, float* dw
   }
   const int ndw = Cs * 9 * Cb;
   DmOrderedSum a = {ws, n, nblocks, n, ndw, n, dw, dbias, nullptr, nullptr};
-  return dm_launch_ordered_sum(a, st);
+  return dm_finish_ordered_sum(a, deferred, st);
 }

@@ -710,11 +710,11 @@ extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const v
 }
 
 extern "C" int dm_groupnorm_param_grads(const dm_gn_desc* d, const float* param_partials, float* dgamma, float* dbeta,
-                                        float* dupstream_bias, void* stream) {
+                                        float* dupstream_bias, dm_sum_item* deferred, void* stream) {
   int rc = check_desc(d, "dm_groupnorm_param_grads");
   if (rc) return rc;
   DM_REQUIRE(param_partials && dgamma && dbeta, DM_ERR_ARG, "dm_groupnorm_param_grads: null argument");
   const int C = d->C1 + d->C2;
   DmOrderedSum a = {param_partials, 3L * C, d->B, dupstream_bias ? 3 * C : 2 * C, C, 2 * C, dbeta, dgamma, dupstream_bias, nullptr};
-  return dm_launch_ordered_sum(a, (hipStream_t)stream);
+  return dm_finish_ordered_sum(a, deferred, (hipStream_t)stream);
 }

@@ -437,30 +437,39 @@ __global__ __launch_bounds__(NT) void colsum_part_kernel(const bf16_t* __restric
   }
 }
 
-// ---- ordered sum of partial vectors (see DmOrderedSum): one workgroup = 64 elements x 16 waves; wave w adds the
-// partials w, w + 16, ... in order, the 16 run sums are then added in wave order
-constexpr int OS_WAVES = 16;
-__global__ __launch_bounds__(64 * OS_WAVES) void ordered_sum_kernel(const DmOrderedSum a) {
+// ---- ordered sums of partial vectors (dm_sum_item), any number of them in one launch: one workgroup = 64 elements
+// of one item x 16 waves; wave w adds the partials w, w + 16, ... in order, the 16 run sums are then added in wave
+// order. The item table travels by value in the kernel arguments.
+constexpr int OS_WAVES = 16, OS_MAX_ITEMS = 40;
+struct OrderedSumGroup {
+  dm_sum_item it[OS_MAX_ITEMS];
+  int tile0[OS_MAX_ITEMS];   // first 64-element tile of each item in the launch grid
+  int count;
+};
+__global__ __launch_bounds__(64 * OS_WAVES) void ordered_sum_kernel(const OrderedSumGroup g) {
   __shared__ float red[OS_WAVES][64];
+  int p = 0;
+  while (p + 1 < g.count && g.tile0[p + 1] <= (int)blockIdx.x) ++p;
+  const dm_sum_item& a = g.it[p];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + lane;
+  const int e = (blockIdx.x - g.tile0[p]) * 64 + lane;
   float s = 0.f;
   if (e < a.n) {
-    const float* p = a.part + e;
+    const float* src = a.part + e;
     int q = w;
     for (; q + 3 * OS_WAVES < a.nparts; q += 4 * OS_WAVES) {
-      const float v0 = p[(size_t)q * a.stride], v1 = p[(size_t)(q + OS_WAVES) * a.stride];
-      const float v2 = p[(size_t)(q + 2 * OS_WAVES) * a.stride], v3 = p[(size_t)(q + 3 * OS_WAVES) * a.stride];
+      const float v0 = src[(size_t)q * a.stride], v1 = src[(size_t)(q + OS_WAVES) * a.stride];
+      const float v2 = src[(size_t)(q + 2 * OS_WAVES) * a.stride], v3 = src[(size_t)(q + 3 * OS_WAVES) * a.stride];
       s += v0; s += v1; s += v2; s += v3;
     }
-    for (; q < a.nparts; q += OS_WAVES) s += p[(size_t)q * a.stride];
+    for (; q < a.nparts; q += OS_WAVES) s += src[(size_t)q * a.stride];
   }
   red[w][lane] = s;
   __syncthreads();
   if (w || e >= a.n) return;
   float t = red[0][lane];
 #pragma unroll
-  for (int g = 1; g < OS_WAVES; ++g) t += red[g][lane];
+  for (int k = 1; k < OS_WAVES; ++k) t += red[k][lane];
   if (e < a.s1) {
     if (a.out0) a.out0[e] += t;
     if (a.dual0) a.dual0[e] += t;
@@ -700,11 +709,32 @@ extern "C" int dm_transpose_conv_weights(const void* src, void* dst, const dm_wt
   return DM_OK;
 }
 
-int dm_launch_ordered_sum(const DmOrderedSum& a, hipStream_t st) {
-  DM_REQUIRE(a.part && a.nparts > 0 && a.n > 0 && a.s1 >= 0 && a.s1 <= a.s2 && a.s2 <= a.n, DM_ERR_ARG, "ordered sum: bad argument");
-  hipLaunchKernelGGL(ordered_sum_kernel, dim3(dm_cdiv(a.n, 64)), dim3(64 * OS_WAVES), 0, st, a);
-  DM_CHECK_LAUNCH();
+extern "C" int dm_ordered_sum_group(const dm_sum_item* items, int n_items, void* stream) {
+  DM_REQUIRE(items && n_items > 0, DM_ERR_ARG, "dm_ordered_sum_group: no items");
+  for (int i0 = 0; i0 < n_items; i0 += OS_MAX_ITEMS) {
+    OrderedSumGroup g;
+    g.count = n_items - i0 < OS_MAX_ITEMS ? n_items - i0 : OS_MAX_ITEMS;
+    int tiles = 0;
+    for (int i = 0; i < g.count; ++i) {
+      const dm_sum_item& a = items[i0 + i];
+      DM_REQUIRE(a.part && a.nparts > 0 && a.n > 0 && a.s1 >= 0 && a.s1 <= a.s2 && a.s2 <= a.n && a.stride >= a.n, DM_ERR_ARG,
+                 "dm_ordered_sum_group: item %d is malformed", i0 + i);
+      g.it[i] = a;
+      g.tile0[i] = tiles;
+      tiles += dm_cdiv(a.n, 64);
+    }
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(tiles), dim3(64 * OS_WAVES), 0, (hipStream_t)stream, g);
+    DM_CHECK_LAUNCH();
+  }
   return DM_OK;
+}
+
+int dm_finish_ordered_sum(const DmOrderedSum& a, dm_sum_item* deferred, hipStream_t st) {
+  if (deferred) {
+    *deferred = a;
+    return DM_OK;
+  }
+  return dm_ordered_sum_group(&a, 1, (void*)st);
 }
 
 // rows per workgroup of the partial-sum kernel: about 1024 workgroups in all, at least 128 rows each
@@ -721,7 +751,7 @@ extern "C" long dm_colsum_ws_floats(long M, int C) {
   return (long)dm_cdiv(M, colsum_rows_per_block(M, C)) * C;
 }
 
-static int colsum_bf16(const void* x, float* out, float* out2, long M, int C, float* ws, void* stream) {
+static int colsum_bf16(const void* x, float* out, float* out2, long M, int C, float* ws, dm_sum_item* deferred, void* stream) {
   DM_REQUIRE(x && out && ws && M > 0 && C > 0, DM_ERR_ARG, "dm_colsum_bf16: bad argument");
   DM_REQUIRE(C % 8 == 0, DM_ERR_SHAPE, "dm_colsum_bf16: C=%d must be a multiple of 8", C);
   DM_REQUIRE((uintptr_t)x % 16 == 0, DM_ERR_ARG, "dm_colsum_bf16: misaligned tensor");
@@ -731,14 +761,15 @@ static int colsum_bf16(const void* x, float* out, float* out2, long M, int C, fl
   hipLaunchKernelGGL(colsum_part_kernel, dim3(dm_cdiv(C, 64), chunks), dim3(NT), 0, st, (const bf16_t*)x, ws, M, C, rpb);
   DM_CHECK_LAUNCH();
   DmOrderedSum a = {ws, C, chunks, C, C, C, out, nullptr, nullptr, out2};
-  return dm_launch_ordered_sum(a, st);
+  return dm_finish_ordered_sum(a, deferred, st);
 }
-extern "C" int dm_colsum_bf16(const void* x, float* out, long M, int C, float* ws, void* stream) {
-  return colsum_bf16(x, out, nullptr, M, C, ws, stream);
+extern "C" int dm_colsum_bf16(const void* x, float* out, long M, int C, float* ws, dm_sum_item* deferred, void* stream) {
+  return colsum_bf16(x, out, nullptr, M, C, ws, deferred, stream);
 }
-extern "C" int dm_colsum_bf16_dual(const void* x, float* out, float* out2, long M, int C, float* ws, void* stream) {
+extern "C" int dm_colsum_bf16_dual(const void* x, float* out, float* out2, long M, int C, float* ws, dm_sum_item* deferred,
+                                   void* stream) {
   DM_REQUIRE(out2, DM_ERR_ARG, "dm_colsum_bf16_dual: null second output");
-  return colsum_bf16(x, out, out2, M, C, ws, stream);
+  return colsum_bf16(x, out, out2, M, C, ws, deferred, stream);
 }
 extern "C" int dm_colsum_f32(const float* x, float* out, int R, int C, void* stream) {
   DM_REQUIRE(x && out && R > 0 && C > 0, DM_ERR_ARG, "dm_colsum_f32: bad argument");

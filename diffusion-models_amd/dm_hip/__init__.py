@@ -35,6 +35,12 @@ class LinearItem(ctypes.Structure):
                 ("db", c_void_p), ("N", c_int)]
 
 
+class SumItem(ctypes.Structure):
+    """dm_sum_item: one ordered sum of partial vectors into up to three accumulating outputs."""
+    _fields_ = [("part", c_void_p), ("stride", c_long), ("nparts", c_int), ("n", c_int), ("s1", c_int), ("s2", c_int),
+                ("out0", c_void_p), ("out1", c_void_p), ("out2", c_void_p), ("dual0", c_void_p)]
+
+
 class WtItem(ctypes.Structure):
     """dm_wt_item: one weight of a batched forward->data-gradient re-layout (element offset, dims, first tile)."""
     _fields_ = [("offset", c_long), ("Cout", c_int), ("T", c_int), ("Cin", c_int), ("tile_begin", c_int)]
@@ -50,18 +56,19 @@ _SIGNATURES = {
     "dm_pack_conv_weight": (c_int, [P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, P, P]),
     "dm_transpose_conv_weights": (c_int, [P, P, P, c_int, c_int, P]),
     "dm_colsum_ws_floats": (c_long, [c_long, c_int]),
-    "dm_colsum_bf16": (c_int, [P, P, c_long, c_int, P, P]),
-    "dm_colsum_bf16_dual": (c_int, [P, P, P, c_long, c_int, P, P]),
+    "dm_ordered_sum_group": (c_int, [P, c_int, P]),
+    "dm_colsum_bf16": (c_int, [P, P, c_long, c_int, P, P, P]),
+    "dm_colsum_bf16_dual": (c_int, [P, P, P, c_long, c_int, P, P, P]),
     "dm_colsum_f32": (c_int, [P, P, c_int, c_int, P]),
     "dm_in_conv_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dm_out_conv_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dm_out_conv_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "dm_edge_conv_wgrad_ws_floats": (c_long, [c_int] * 6),
-    "dm_edge_conv_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "dm_edge_conv_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "dm_groupnorm_ws_floats": (c_long, [ctypes.POINTER(GnDesc)]),
     "dm_groupnorm_act_fwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 11),
     "dm_groupnorm_act_bwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 15 + [c_int, P, P]),
-    "dm_groupnorm_param_grads": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 5),
+    "dm_groupnorm_param_grads": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 6),
     "dm_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "dm_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "dm_timestep_embed": (c_int, [P, P, P, c_int, c_int, P]),

@@ -9,7 +9,7 @@ import ctypes
 import torch
 from torch.autograd import Function
 
-from . import ConvDesc, GnDesc, LinearItem, check, lib
+from . import ConvDesc, GnDesc, LinearItem, SumItem, check, lib
 
 BF16 = torch.bfloat16
 CL = torch.channels_last
@@ -32,6 +32,48 @@ GRAD_READY = None
 SIDE_WGRAD = 0   # number of side streams to rotate over (0: off)
 _SIDE = {}
 _SIDE_NEXT = 0
+
+
+class SumCollector:
+    """Deferred ordered sums (dm_sum_item): the producers of parameter-gradient partials fill in one item each
+    instead of launching their own sum, and flush() runs all of them in ONE launch. The partial buffers are kept
+    alive until then. flush() must be called on a stream that is ordered after every producer."""
+
+    def __init__(self, capacity=512):
+        self.items = (SumItem * capacity)()
+        self.count = 0
+        self.keep = []
+
+    def slot(self, *tensors):
+        """ctypes reference to the next free item; `tensors` are the scratch buffers the item will point into."""
+        if self.count == len(self.items):
+            raise RuntimeError("SumCollector: more deferred sums than its capacity; flush() more often")
+        ref = ctypes.byref(self.items[self.count])
+        self.count += 1
+        self.keep.extend(tensors)
+        return ref
+
+    def flush(self):
+        if self.count:
+            cur = torch.cuda.current_stream()
+            for t in self.keep:
+                t.record_stream(cur)
+            check(lib.dm_ordered_sum_group(self.items, self.count, cur.cuda_stream))
+        self.count = 0
+        self.keep = []
+
+
+# When set (a SumCollector) and DIRECT_GRADS is on, the ordered sums behind bias / GroupNorm-affine / edge-conv
+# gradients are collected there instead of being launched one by one; whoever sets it calls flush() after backward
+# (after joining the side streams) and before anything reads those gradients.
+PENDING_SUMS = None
+
+
+def _deferred(direct, *tensors):
+    """The `deferred` argument of a producer: a collector slot when sums are being collected, else None (sum now)."""
+    if direct and PENDING_SUMS is not None:
+        return PENDING_SUMS.slot(*tensors)
+    return None
 
 
 def side_stream(device, index=0):
@@ -262,10 +304,12 @@ class _ConvFn(Function):
             cws = _scratch(dy.device, lib.dm_colsum_ws_floats(M, Cout), stream_w)
             if tsink is not None:
                 # the twin's convolution produced the other term of the same sum (and ran with bias_grad=False)
-                check(lib.dm_colsum_bf16_dual(dy.data_ptr(), dbf.data_ptr(), tsink.data_ptr(), M, Cout, cws.data_ptr(), st_w))
+                check(lib.dm_colsum_bf16_dual(dy.data_ptr(), dbf.data_ptr(), tsink.data_ptr(), M, Cout, cws.data_ptr(),
+                                              _deferred(True, cws), st_w))
                 _grad_done(twin)
             else:
-                check(lib.dm_colsum_bf16(dy.data_ptr(), dbf.data_ptr(), M, Cout, cws.data_ptr(), st_w))
+                check(lib.dm_colsum_bf16(dy.data_ptr(), dbf.data_ptr(), M, Cout, cws.data_ptr(),
+                                         _deferred(bsink is not None and twin is None, cws), st_w))
                 if twin is not None:
                     g = dbf.detach().to(twin.dtype)
                     if twin.grad is None:
@@ -371,11 +415,11 @@ class _GroupNormActFn(Function):
                                        _p(ss32), _p(pre32), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(),
                                        _p(dextra), dx1.data_ptr(), _p(dx2), _p(dss), _p(dpre), partials.data_ptr(),
                                        int(dub is not None), ws.data_ptr(), _stream()))
-        # the batch sums of the per-sample terms feed nothing but the optimizer: off the critical path when the
-        # gradients go straight to their buffers
-        st_p, _ = _param_stream((partials,), direct and (dub is None or ub_sink is not None))
+        # the batch sums of the per-sample terms feed nothing but the optimizer: collected for one grouped launch
+        # after backward when the gradients go straight to their buffers, else summed right here
+        all_direct = direct and (dub is None or ub_sink is not None)
         check(lib.dm_groupnorm_param_grads(ctypes.byref(d), partials.data_ptr(), dg.data_ptr(), db_.data_ptr(),
-                                           _p(dub), st_p))
+                                           _p(dub), _deferred(all_direct, partials), _stream()))
         if ub_sink is not None:
             _grad_done(ub)
             dub = None
@@ -634,7 +678,7 @@ def _edge_wgrad(small, big, weight, bias, shape, big_is_output, wait_for):
     st, stream_w = _param_stream(wait_for, direct)
     ws = _scratch(dev, lib.dm_edge_conv_wgrad_ws_floats(B, Cs, H, W, Cb, 1 if big_is_output else 0), stream_w)
     check(lib.dm_edge_conv_wgrad(small.data_ptr(), big.data_ptr(), dw.data_ptr(), _p(db), B, Cs, H, W, Cb,
-                                 1 if big_is_output else 0, ws.data_ptr(), st))
+                                 1 if big_is_output else 0, ws.data_ptr(), _deferred(direct, ws), st))
     if direct:
         _grad_done(weight)
         if bias is not None:

@@ -89,6 +89,7 @@ class TrainStep:
             self.reducer.extra_streams = lambda: [ops.side_stream(dev, 0)] + [
                 s for s in ops.side_streams(dev) if s is not ops.side_stream(dev, 0)]
         self._in_backward = False
+        self._sums = ops.SumCollector()
         self._param_index = {id(p): i for i, (_, p) in enumerate(self.arena.params)}
         if self.world > 1:
             # gradients that autograd accumulates itself report through this hook; gradients the kernels write in
@@ -164,17 +165,26 @@ class TrainStep:
         communication and can be captured into a HIP graph on every rank."""
         self.reducer.begin()
         self._in_backward = True
-        ops.DIRECT_GRADS, ops.GRAD_READY = True, (self._on_grad_ready if (self.world > 1 and overlap) else None)
+        overlapped = self.world > 1 and overlap
+        ops.DIRECT_GRADS, ops.GRAD_READY = True, (self._on_grad_ready if overlapped else None)
         ops.SIDE_WGRAD = int(self.side_wgrad)
+        # The ordered sums behind bias / GroupNorm-affine / edge-conv gradients run as ONE launch after backward -
+        # except when buckets are all-reduced while backward runs: those gradients are spread over every bucket, so
+        # each is then summed where it is produced and its bucket can leave early.
+        ops.PENDING_SUMS = None if overlapped else self._sums
         try:
             loss.backward()
+        except BaseException:
+            self._sums.count, self._sums.keep = 0, []   # a failed backward leaves nothing to sum
+            raise
         finally:
-            ops.DIRECT_GRADS, ops.GRAD_READY, ops.SIDE_WGRAD = False, None, 0
+            ops.DIRECT_GRADS, ops.GRAD_READY, ops.SIDE_WGRAD, ops.PENDING_SUMS = False, None, 0, None
             self._in_backward = False
         if self.side_wgrad:
             # the weight/bias gradient kernels ran on the second stream: join before anything reads the arena
             for side in ops.side_streams(self.arena.data.device):
                 torch.cuda.current_stream().wait_stream(side)
+        self._sums.flush()
 
     def _reduce(self):
         """Finish the data-parallel mean of the gradient arena (launches whatever buckets are still outstanding)."""

@@ -29,6 +29,27 @@ typedef enum dm_status {
 } dm_status;
 
 const char* dm_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Ordered sums. Parameter gradients that are sums over samples, pixels or workgroups (bias gradients, GroupNorm
+ * affine gradients, edge-conv weights) are never accumulated with float atomics: the producing kernel leaves partial
+ * vectors in scratch and an ordered sum adds them up in a fixed order, so a training step is bitwise reproducible.
+ *   s[e] = sum_q part[q * stride + e], q = 0 .. nparts-1, e < n
+ *   e in [0, s1): out0[e] += s (and dual0[e] += s when given); [s1, s2): out1[e - s1] += s; [s2, n): out2[e - s2] += s
+ * (a null output skips its segment). The operators below that produce such sums take a `dm_sum_item* deferred`:
+ * null = the ordered sum is launched at once on the same stream; non-null = the item is filled in instead and the
+ * caller runs any number of them later in ONE launch with dm_ordered_sum_group, on a stream ordered after the
+ * producers (the scratch must stay untouched until then). `items` is a HOST array. */
+typedef struct dm_sum_item {
+  const float* part;
+  long stride;
+  int nparts, n, s1, s2;
+  float* out0;
+  float* out1;
+  float* out2;
+  float* dual0;
+} dm_sum_item;
+int dm_ordered_sum_group(const dm_sum_item* items, int n_items, void* stream);
 int dm_abi_version(void);
 /* run-time switches: "conv_patch" (default 1): 3x3 stride-1 convs use the LDS-staged-patch kernel;
  * "wgrad_row3" (default 1): their weight gradients use the kernel that shares one staged input row among 3 taps;
@@ -96,10 +117,11 @@ int dm_transpose_conv_weights(const void* src, void* dst, const dm_wt_item* item
  * floats; row chunks are summed into it with plain stores and added to out in chunk order (no float atomics).
  * The bias gradient autograd computes for nn.Conv2d (modeling/blocks.py:26,28,45,89,110). */
 long dm_colsum_ws_floats(long M, int C);
-int dm_colsum_bf16(const void* x, float* out, long M, int C, float* ws, void* stream);
+int dm_colsum_bf16(const void* x, float* out, long M, int C, float* ws, dm_sum_item* deferred, void* stream);
 /* the same sums added into two outputs: a block's conv2 and res_proj (modeling/blocks.py:28,45,74-75) produce the
  * two terms of one sum, so their bias gradients are the same column sums */
-int dm_colsum_bf16_dual(const void* x, float* out, float* out2, long M, int C, float* ws, void* stream);
+int dm_colsum_bf16_dual(const void* x, float* out, float* out2, long M, int C, float* ws, dm_sum_item* deferred,
+                        void* stream);
 /* out[c] += sum_r x[r][c]  (x fp32 [R][C]) */
 int dm_colsum_f32(const float* x, float* out, int R, int C, void* stream);
 
@@ -124,7 +146,7 @@ int dm_out_conv_dgrad(const float* dy, const float* w, void* dh, int B, int Cs, 
  * added to dw / dbias in workgroup order (no float atomics). */
 long dm_edge_conv_wgrad_ws_floats(int B, int Cs, int H, int W, int Cb, int big_is_output);
 int dm_edge_conv_wgrad(const float* small, const void* big, float* dw, float* dbias, int B, int Cs, int H, int W,
-                       int Cb, int big_is_output, float* ws, void* stream);
+                       int Cb, int big_is_output, float* ws, dm_sum_item* deferred, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * GroupNorm (+ per-sample scale/shift or pre-add) (+ SiLU), fused; channel axis may be two sources.
@@ -162,7 +184,7 @@ int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const void* x2, co
                          const void* dy, const void* dextra, void* dx1, void* dx2, float* dscale_shift,
                          float* dpre_add, float* param_partials, int want_upstream_bias, float* ws, void* stream);
 int dm_groupnorm_param_grads(const dm_gn_desc* d, const float* param_partials, float* dgamma, float* dbeta,
-                             float* dupstream_bias, void* stream);
+                             float* dupstream_bias, dm_sum_item* deferred, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Spatial self-attention core. Replaces F.scaled_dot_product_attention and the view/permute/contiguous
