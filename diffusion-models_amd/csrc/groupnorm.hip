@@ -17,8 +17,16 @@
 // The workspace is pure scratch (written before it is read in every call), so one buffer serves every call.
 // The channel axis may be the concatenation of two tensors (x1 | x2).
 #include "dm_common.h"
+#include <mutex>
 
 extern int g_dm_gn_fused;
+
+// Scratch of the entry point that allocates nothing (dm_groupnorm_act_fwd_noalloc): a fixed device array that
+// stands in for the caller-provided workspace. Every GPU the library runs on holds its own copy at its own
+// address; host code must not use the array's name as a pointer - it resolves the address once per device with
+// hipGetSymbolAddress (scratch_for_current_device) and passes that to the kernels.
+constexpr long NOALLOC_WS_FLOATS = 1L << 20;   // 4 MiB per GPU: covers B * C <= 349525 (e.g. batch 256 x 1024 channels)
+static __device__ __align__(256) float scratch[NOALLOC_WS_FLOATS];
 
 namespace {
 
@@ -638,6 +646,35 @@ void fill(GnArgs& a, const dm_gn_desc* d) {
 
 }  // namespace
 
+// per-device address of `scratch`, resolved on first use with that device current
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static float* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+static std::mutex g_scratch_mutex;
+
+static int scratch_for_current_device(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  DM_REQUIRE(e == hipSuccess, DM_ERR_LAUNCH, "no-allocation scratch: hipGetDevice failed: %s", hipGetErrorString(e));
+  DM_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES, DM_ERR_UNSUPPORTED, "no-allocation scratch: device index %d >= %d", dev, NOALLOC_MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    float* p = nullptr;
+    e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    DM_REQUIRE(e == hipSuccess && p, DM_ERR_LAUNCH, "no-allocation scratch: hipGetSymbolAddress failed on device %d: %s", dev,
+               hipGetErrorString(e));
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return DM_OK;
+}
+
+extern "C" int dm_noalloc_init(void) {
+  float* p = nullptr;
+  return scratch_for_current_device(&p);
+}
+
+extern "C" long dm_groupnorm_noalloc_max_ws_floats(void) { return NOALLOC_WS_FLOATS; }
+
 extern "C" long dm_groupnorm_ws_floats(const dm_gn_desc* d) {
   return d ? 3L * d->B * (d->C1 + d->C2) : 0;
 }
@@ -669,6 +706,22 @@ extern "C" int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const v
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(NT), 0, st, a);
   DM_CHECK_LAUNCH();
   return DM_OK;
+}
+
+extern "C" int dm_groupnorm_act_fwd_noalloc(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma,
+                                            const float* beta, const float* scale_shift, const float* pre_add, void* y,
+                                            float* mean, float* rstd, void* stream) {
+  int rc = check_desc(d, "dm_groupnorm_act_fwd_noalloc");
+  if (rc) return rc;
+  const long need = dm_groupnorm_ws_floats(d);
+  DM_REQUIRE(need <= NOALLOC_WS_FLOATS, DM_ERR_UNSUPPORTED,
+             "dm_groupnorm_act_fwd_noalloc: B * C = %ld needs %ld workspace floats, the built-in scratch holds %ld "
+             "(use dm_groupnorm_act_fwd with a workspace of your own)", (long)d->B * (d->C1 + d->C2), need, NOALLOC_WS_FLOATS);
+  float* ws = nullptr;
+  rc = scratch_for_current_device(&ws);
+  if (rc) return rc;
+  // the per-channel sums are written before they are read in every call: nothing has to be cleared
+  return dm_groupnorm_act_fwd(d, x1, x2, gamma, beta, scale_shift, pre_add, y, mean, rstd, ws, stream);
 }
 
 extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma,

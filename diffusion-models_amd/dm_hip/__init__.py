@@ -67,6 +67,9 @@ _SIGNATURES = {
     "dm_edge_conv_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "dm_groupnorm_ws_floats": (c_long, [ctypes.POINTER(GnDesc)]),
     "dm_groupnorm_act_fwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 11),
+    "dm_noalloc_init": (c_int, []),
+    "dm_groupnorm_noalloc_max_ws_floats": (c_long, []),
+    "dm_groupnorm_act_fwd_noalloc": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 10),
     "dm_groupnorm_act_bwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 15 + [c_int, P, P]),
     "dm_groupnorm_param_grads": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 6),
     "dm_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),

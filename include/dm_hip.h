@@ -171,6 +171,19 @@ long dm_groupnorm_ws_floats(const dm_gn_desc* d);
 int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma, const float* beta,
                          const float* scale_shift, const float* pre_add, void* y, float* mean, float* rstd, float* ws,
                          void* stream);
+/* The forward operator for callers that cannot allocate or pass a workspace (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): the same kernels with a fixed scratch array inside the library
+ * standing in for `ws`. It has no counterpart in the reference. Nothing is allocated or freed, here or in any call
+ * it makes. Limit: dm_groupnorm_ws_floats(d) <= dm_groupnorm_noalloc_max_ws_floats() (1 Mi floats = 4 MiB held per
+ * GPU until the process ends; e.g. batch 256 x 1024 channels); larger shapes are rejected with DM_ERR_UNSUPPORTED.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race.
+ * dm_noalloc_init() resolves the array's address for the CURRENT device (the first call of the operator on a device
+ * does it otherwise); call it once per device before capturing a graph. */
+int dm_noalloc_init(void);
+long dm_groupnorm_noalloc_max_ws_floats(void);
+int dm_groupnorm_act_fwd_noalloc(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma,
+                                 const float* beta, const float* scale_shift, const float* pre_add, void* y,
+                                 float* mean, float* rstd, void* stream);
 /* dx1|dx2 bf16 (= GN backward + dextra, dextra optional bf16 [B][HW][C]); dscale_shift fp32 [B][2C] and dpre_add
  * fp32 [B][C] are written when present. param_partials (fp32 [B][3][C], written): every sample's contribution to
  * dbeta ([b][0][c]), dgamma ([b][1][c]) and, when want_upstream_bias (excludes dextra), the sum of dx over the
