@@ -293,15 +293,20 @@ def dump_diffusion():
 # ----------------------------------------------------------------------------------------------
 # 5. train-step fixture: the caller semantics of train.py:429-452 re-stated around the imported reference
 #    (train.py itself needs torchvision/wandb/fire/diffusers, which are absent here).
-def dump_train_steps():
+def dump_train_steps(kind="vp"):
+    """kind 'vp': cosine-beta noise prediction (train_steps_tiny.npz); 'rf': rectified flow, velocity target x - eps
+    (train_steps_tiny_rf.npz) - the objective rf_cifar_long.json / rf_mnist.json train with."""
     m = get_model("unet", **TINY_CFG)
-    load_det_weights(m, 800)
+    load_det_weights(m, 800 if kind == "vp" else 810)
     m.train()
-    sched = get_scheduler("beta", schedule="cosine", cos_s=0.008, cos_max_beta=0.999, n_steps=1000)
+    if kind == "vp":
+        sched = get_scheduler("beta", schedule="cosine", cos_s=0.008, cos_max_beta=0.999, n_steps=1000)
+    else:
+        sched = get_scheduler("rectified_flow", n_steps=1000)
     opt = torch.optim.AdamW(m.parameters(), lr=2e-4, betas=(0.9, 0.99))
-    rs = np.random.RandomState(801)
+    rs = np.random.RandomState(801 if kind == "vp" else 811)
     B, steps = 8, 3
-    res = {"steps": np.array(steps), "seed": np.array(800)}
+    res = {"steps": np.array(steps), "seed": np.array(800 if kind == "vp" else 810)}
     names = [k for k, _ in m.named_parameters()]
     for s in range(steps):
         x = torch.from_numpy(rs.uniform(-1, 1, size=(B, 3, 16, 16)).astype(np.float32))
@@ -311,7 +316,7 @@ def dump_train_steps():
         t = torch.from_numpy(rs.randint(0, 1000, size=(B,)).astype(np.int64))
         x_t = sched.diffuse(x, t, eps)
         pred = m(x_t, t, cls=cls, uncond_mask=mask)
-        loss = torch.nn.functional.mse_loss(pred, eps)
+        loss = torch.nn.functional.mse_loss(pred, eps if kind == "vp" else x - eps)
         loss.backward()
         gnorm = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
         opt.step()
@@ -322,8 +327,86 @@ def dump_train_steps():
         res[f"psample{s}"] = np.stack([p.detach().flatten()[:8].numpy().copy() if p.numel() >= 8
                                        else np.pad(p.detach().flatten().numpy(), (0, 8 - p.numel()))
                                        for p in m.parameters()])
+    if kind == "rf":
+        # the scheduler's own get_loss on the first batch, with its RNG order (eps, then t) from a seeded generator
+        m2 = get_model("unet", **TINY_CFG)
+        load_det_weights(m2, 810)
+        m2.train()
+        gen = torch.Generator().manual_seed(5)
+        res["getloss_x"], res["getloss_cls"] = res["x0"], res["cls0"]
+        res["getloss_value"] = sched.get_loss(res["x0"], m2, gen=gen, cls=res["cls0"]).detach()
+        gen = torch.Generator().manual_seed(5)
+        res["getloss_eps"] = torch.randn_like(res["x0"], generator=gen)
+        res["getloss_t"] = torch.randint(0, 1000, size=(B,), generator=gen)
     res["param_names"] = np.array(names)
-    npz("train_steps_tiny.npz", **res)
+    npz("train_steps_tiny.npz" if kind == "vp" else "train_steps_tiny_rf.npz", **res)
+
+
+# ----------------------------------------------------------------------------------------------
+# 5b. images generated THROUGH THE NETWORK (train.py:476-504 / save_fid_eval.py:163-172: pred_fn = model.get_pred_fn,
+#     sampler.sample, clip) for every sampler family and both beta schedules, fp32 on the CPU as the reference
+#     samples. An untrained network is a chaotic map under 50 sampler steps (fp32 summation-order noise of 1e-6 grows
+#     to 3e-2), so the networks here are TRAINED by the reference first (the train.py:429-452 step, 600 steps on the
+#     structured toy data of parity.py) - a denoiser is a contraction towards the data - and their weights are stored
+#     rounded to bf16 (exactly representable in both implementations). The DDPM noise stream is stored as well.
+MINI_CFG = dict(TINY_CFG, block_out_channels=[64, 64])
+SAMPLE_TRAIN = dict(steps=600, batch=16, lr=5e-4, weights_seed=920)
+
+
+def _train_mini(kind):
+    sys.path.insert(0, os.path.dirname(HERE))
+    from parity import curve_batches
+    from itertools import islice
+    m = get_model("unet", **MINI_CFG)
+    load_det_weights(m, SAMPLE_TRAIN["weights_seed"])
+    m.train()
+    sched = get_scheduler("beta", schedule="linear", n_steps=1000) if kind == "vp" else get_scheduler("rectified_flow", n_steps=1000)
+    opt = torch.optim.AdamW(m.parameters(), lr=SAMPLE_TRAIN["lr"], betas=(0.9, 0.99))
+    for s, (x, cls, mask, eps, t) in enumerate(islice(curve_batches(), SAMPLE_TRAIN["steps"])):
+        pred = m(sched.diffuse(x, t, eps), t, cls=cls, uncond_mask=mask)
+        loss = torch.nn.functional.mse_loss(pred, eps if kind == "vp" else x - eps)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        m.zero_grad()
+        if s % 100 == 0:
+            print("  ", kind, "train step", s, float(loss), flush=True)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    return m.eval(), float(loss)
+
+
+def dump_samples():
+    res = {}
+    gen = torch.Generator().manual_seed(42)
+    z = torch.randn(8, 3, 16, 16, generator=gen)
+    cls = torch.randint(0, 10, (8,), generator=torch.Generator().manual_seed(42))
+    res["z"], res["cls"] = z, cls
+    lin = get_scheduler("beta", schedule="linear", n_steps=1000)
+    cos = get_scheduler("beta", schedule="cosine", cos_s=0.008, cos_max_beta=0.999, n_steps=1000)
+    rf = get_scheduler("rectified_flow", n_steps=1000)
+    for kind in ("vp", "rf"):
+        m, last = _train_mini(kind)
+        res[f"{kind}_final_train_loss"] = np.array(last)
+        for k, p in m.named_parameters():
+            res[f"w_{kind}_{k}"] = p.detach().to(torch.bfloat16).view(torch.int16).numpy()
+        with torch.no_grad():
+            pred = m.get_pred_fn(cond=cls, guidance_scale=1.0)
+            if kind == "vp":
+                res["ddim50_lin"] = torch.clip(get_sampler("ddim", n_steps=50).sample(z, lin, pred), -1, 1)
+                res["ddim50_cos"] = torch.clip(get_sampler("ddim", n_steps=50).sample(z, cos, pred), -1, 1)
+                z4 = z[:4].clone()   # (the stored noise stream is the bulk of this fixture: 4 images, 50 steps)
+                pred4 = m.get_pred_fn(cond=cls[:4], guidance_scale=1.0)
+                res["ddpm50_lin"] = torch.clip(get_sampler("ddpm", n_steps=50).sample(z4, lin, pred4, seed=9), -1, 1)
+                g = torch.Generator()
+                g.manual_seed(9)
+                res["noise_ddpm50_lin"] = torch.stack([torch.randn_like(z4, generator=g) for _ in range(49)])
+                res["ddim20_lin_g2"] = torch.clip(
+                    get_sampler("ddim", n_steps=20).sample(z, lin, m.get_pred_fn(cond=cls, guidance_scale=2.0)), -1, 1)
+            else:
+                res["euler50_rf"] = torch.clip(get_sampler("euler", n_steps=50).sample(z, rf, pred), -1, 1)
+    npz("samples.npz", **res)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -364,6 +447,10 @@ if __name__ == "__main__":
     if "diffusion" in which:
         dump_diffusion()
     if "train" in which:
-        dump_train_steps()
+        dump_train_steps("vp")
+    if "train_rf" in which:
+        dump_train_steps("rf")
+    if "samples" in which:
+        dump_samples()
     if "curve" in which:
         dump_train_curve()

@@ -28,6 +28,17 @@ TINY_ATTN_CFG = dict(TINY_CFG, down_block_types=["UNetDownBlock", "UNetAttnDownB
                      up_block_types=["UNetAttnUpBlock", "UNetUpBlock"], embedding_mixing="addition")
 
 
+# the networks of tests/golden/samples.npz (trained by the reference, weights stored rounded to bf16)
+MINI_CFG = dict(TINY_CFG, block_out_channels=[64, 64])
+
+
+def trained_mini_state(g, kind):
+    """{parameter name: fp32 tensor} of the 'vp' or 'rf' network stored in samples.npz (bf16 bit patterns)."""
+    prefix = f"w_{kind}_"
+    return {k[len(prefix):]: torch.from_numpy(np.ascontiguousarray(g[k])).view(torch.bfloat16).float()
+            for k in g.files if k.startswith(prefix)}
+
+
 # ---- loss-curve recipe (tests/golden/train_curve_tiny.npz holds the reference's losses for it) -------------
 CURVE = dict(weights_seed=900, data_seed=901, steps=1000, batch=16, n_images=64, lr=5e-4)
 

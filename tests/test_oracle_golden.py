@@ -145,8 +145,9 @@ def test_samplers_bitexact():
     assert abs(float(out.double().sum()) - (-8037.306618)) < 1e-3  # SURVEY known answer
 
 
-def test_train_steps():
-    g = golden("train_steps_tiny.npz")
+@pytest.mark.parametrize("fixture,kind", [("train_steps_tiny.npz", "vp"), ("train_steps_tiny_rf.npz", "rf")])
+def test_train_steps(fixture, kind):
+    g = golden(fixture)
     from modeling import get_model
     m = get_model("unet", **TINY_CFG)
     shapes = [(k, v.shape) for k, v in m.state_dict().items()]
@@ -155,16 +156,53 @@ def test_train_steps():
     names = O.param_names(sd)
     assert names == [str(s) for s in g["param_names"]]
     opt = O.AdamWState({k: sd[k] for k in names}, lr=2e-4)
-    table = O.alpha_sq_from_beta(O.beta_cosine())
+    table = O.alpha_sq_from_beta(O.beta_cosine()) if kind == "vp" else O.rf_sigmas()
+    if kind == "rf":
+        # RectifiedFlowScheduler.get_loss with its own RNG order (eps, then t) on the initial weights
+        gen = torch.Generator().manual_seed(5)
+        eps, t = O.draw_eps_t(T(g["getloss_x"]), 1000, gen)
+        assert np.array_equal(eps.numpy(), g["getloss_eps"]) and np.array_equal(t.numpy(), g["getloss_t"])
+        with torch.no_grad():
+            model = lambda xt, tt, **kw: O.unet_forward(sd, TINY_CFG, xt, tt, **kw)  # noqa: E731
+            assert abs(float(O.loss_rf(model, T(g["getloss_x"]), t, eps, table, cls=T(g["getloss_cls"]))) -
+                       float(g["getloss_value"])) < 1e-5
     for s in range(int(g["steps"])):
         batch = tuple(T(g[f"{k}{s}"]) for k in ("x", "cls", "mask", "eps", "t"))
-        loss, gnorm, _ = O.train_step(sd, TINY_CFG, opt, batch, "vp", table, clip=1.0)
+        loss, gnorm, _ = O.train_step(sd, TINY_CFG, opt, batch, kind, table, clip=1.0)
         assert abs(float(loss) - float(g[f"loss{s}"])) < 1e-5
         assert abs(float(gnorm) - float(g[f"gnorm{s}"])) < 1e-4 * float(g[f"gnorm{s}"])
         pn = np.array([float(sd[k].double().norm()) for k in names])
         assert np.allclose(pn, g[f"pnorm{s}"], rtol=1e-5, atol=1e-6)
         ps = np.stack([np.pad(sd[k].flatten()[:8].numpy(), (0, max(0, 8 - sd[k].numel()))) for k in names])
         assert np.allclose(ps, g[f"psample{s}"], rtol=2e-4, atol=2e-6)
+
+
+def test_samples_through_the_network():
+    """Images generated through reference-trained UNets (pred_fn = guided_pred) by every sampler family, against the
+    reference's images (fp32 on both sides)."""
+    from modeling import get_model
+    from tests.parity import MINI_CFG, trained_mini_state
+    g = golden("samples.npz")
+    z, cls = T(g["z"]), T(g["cls"])
+    lin, cos, rf = O.alpha_sq_from_beta(O.beta_linear()), O.alpha_sq_from_beta(O.beta_cosine()), O.rf_sigmas()
+    base = {k: v.clone() for k, v in get_model("unet", **MINI_CFG).state_dict().items()}
+    outs = {}
+    with torch.no_grad():
+        sd = dict(base, **trained_mini_state(g, "vp"))
+        pred = lambda z_, t_: O.guided_pred(sd, MINI_CFG, z_, t_, cond=cls, guidance_scale=1.0)  # noqa: E731
+        pred4 = lambda z_, t_: O.guided_pred(sd, MINI_CFG, z_, t_, cond=cls[:4], guidance_scale=1.0)  # noqa: E731
+        pred2 = lambda z_, t_: O.guided_pred(sd, MINI_CFG, z_, t_, cond=cls, guidance_scale=2.0)  # noqa: E731
+        noise = T(g["noise_ddpm50_lin"])
+        outs["ddim50_lin"] = O.sample_ddim(z, lin, 50, pred)
+        outs["ddim50_cos"] = O.sample_ddim(z, cos, 50, pred)
+        outs["ddpm50_lin"] = O.sample_ddpm(z[:4], O.beta_linear(), lin, 50, pred4, lambda i: noise[i])
+        outs["ddim20_lin_g2"] = O.sample_ddim(z, lin, 20, pred2)
+        sd_rf = dict(base, **trained_mini_state(g, "rf"))
+        outs["euler50_rf"] = O.sample_euler(z, rf, 50, lambda z_, t_: O.guided_pred(sd_rf, MINI_CFG, z_, t_, cond=cls,
+                                                                                     guidance_scale=1.0))
+    for k, out in outs.items():
+        err = max_abs(torch.clip(out, -1, 1), T(g[k]))
+        assert err < 1e-3, (k, err)   # summation-order differences of the fp32 kernels over 20-50 network evaluations
 
 
 def test_loss_curve_head():
