@@ -347,12 +347,13 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(GnArgs a) {
 
 // ============================================================================================================
 // Single-pass kernels for the common case (channels per group divide 64, at most 1024 pixels per sample).
-// One workgroup = (sample b, 64 channels): it holds that slab of x (and dy) IN REGISTERS - 8 pixels per thread,
-// one thread per pixel lane and 8-channel vector (16 pixels for 32x32 images) - so every tensor is read from memory exactly once and the sums
-// never leave the CU: forward 4 B/element instead of 6, backward 6 (+2 with a residual gradient) instead of 10.
+// One workgroup = (sample b, 64 channels): it holds that slab of x (and dy) IN REGISTERS as packed bf16 - thread =
+// (8-channel vector, pixel lane), PPT pixels per thread - so every tensor is read from memory exactly once and the
+// sums never leave the CU: forward 4 B/element instead of 6, backward 6 (+2 with a residual gradient) instead of 10.
+// PPT is the smallest of 1, 2, 4, 8 that brings the pixel lanes down to 64 (512 threads; 128 lanes = 1024 threads for
+// 513..1024 pixels), so small images still fill a workgroup with waves (an 8x8 image is 64 lanes of one pixel, not
+// one wave holding eight) and the loads of a whole slab are in flight at once.
 // Groups never straddle the slab, so the group statistics are workgroup-local; all sums run in a fixed order.
-constexpr int FS_MAXT = 512;   // threads per workgroup (= pixel lanes * 8): 8 waves, so up to 256 registers per thread
-// pixels per thread: template parameter FS_PPT = 8 (up to 512 pixels per sample) or 16 (up to 1024)
 
 // sums of NV per-thread 8-vectors over all pixel lanes: shuffles inside a wave (lanes with equal tid & 7), then a
 // fixed-order sum over the waves through LDS. Result for channel cc (0..63), quantity k in out[k * 64 + cc].
@@ -384,33 +385,84 @@ __device__ __forceinline__ void slab_block_sum(float (&part)[NV][8], float* red 
   __syncthreads();
 }
 
-template <int FS_PPT>
-__global__ __launch_bounds__(FS_MAXT) void gn_fwd_fused_kernel(GnArgs a) {
-  __shared__ float red[(FS_MAXT / 64) * 2 * 64];
+// element j (0..7) of 8 packed bf16 held as 4 words: a shift or a mask, no conversion instruction; holding the slab
+// as words keeps it at 4 registers per vector (a bf16 vector held across the reduction is widened to one register
+// per element by the compiler)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ float bf16_half(unsigned u, int hi) {
+  return __uint_as_float(hi ? (u & 0xffff0000u) : (u << 16));
+}
+__device__ __forceinline__ float bf16_at(const u32x4_t& w, int j) {
+  const unsigned u = w[j >> 1];
+  return __uint_as_float((j & 1) ? (u & 0xffff0000u) : (u << 16));
+}
+
+// the slab's vector of pixel p (clamped to a valid address; out-of-range lanes hold zeros)
+__device__ __forceinline__ u32x4_t load_slab_x(const GnArgs& a, size_t base, int p, int c, bool cok) {
+  const bool ok = cok && p < a.HW;
+  const u32x4_t v = __builtin_bit_cast(u32x4_t, load_x(a, base + (ok ? p : 0), cok ? c : 0));
+  return ok ? v : u32x4_t{0, 0, 0, 0};
+}
+
+// the same sum in two steps, for kernels that produce the 8 channels of a thread as two halves of 4 (the first
+// half's sums then need no registers while the second half is being worked on): slab_half_to_lds per half h, then
+// slab_sum_finish
+template <int NV>
+__device__ __forceinline__ void slab_half_to_lds(float (&ph)[NV][4], float* red /*[waves][NV][64]*/, int h) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = ph[k][j];
+      t += __shfl_xor(t, 8, 64);
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      ph[k][j] = t;
+    }
+  if (lane < 8) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(wave * NV + k) * 64 + lane * 8 + 4 * h + j] = ph[k][j];
+  }
+}
+template <int NV>
+__device__ __forceinline__ void slab_sum_finish(const float* red, float* out) {
+  const int nw = blockDim.x >> 6;
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV * 64; i += blockDim.x) {
+    float t = 0.f;
+    for (int w = 0; w < nw; ++w) t += red[w * NV * 64 + i];
+    out[i] = t;
+  }
+  __syncthreads();
+}
+
+template <int PPT, int MAXT, bool ACT>
+__global__ __launch_bounds__(MAXT) void gn_fwd_fused_kernel(GnArgs a) {
+  __shared__ float red[(MAXT / 64) * 2 * 64];
   __shared__ float sums[2 * 64];
-  __shared__ float s_mean[64], s_rstd[64];   // per group of the slab (at most 64 / cg <= 16 used... cg >= 1)
+  __shared__ float s_mean[64], s_rstd[64];   // per group of the slab
+  __shared__ float s_ka[64], s_kb[64];
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int v = threadIdx.x & 7, pl = threadIdx.x >> 3, PLN = blockDim.x >> 3;
   const int c = c0 + 8 * v;
   const bool cok = c < a.C;
   const size_t base = (size_t)b * a.HW;
-  bf16x8_t xr[FS_PPT];
+  u32x4_t xr[PPT];   // packed bf16 pairs: 4 registers per 8 channels of a pixel
   float part[2][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
 #pragma unroll
-  for (int i = 0; i < FS_PPT; ++i) {
-    const int p = pl + i * PLN;
-    if (cok && p < a.HW) xr[i] = load_x(a, base + p, c);
-    else xr[i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-  }
+  for (int i = 0; i < PPT; ++i) xr[i] = load_slab_x(a, base, pl + i * PLN, c, cok);
 #pragma unroll
-  for (int i = 0; i < FS_PPT; ++i)
+  for (int i = 0; i < PPT; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float f = (float)xr[i][j]; part[0][j] += f; part[1][j] += f * f; }
+    for (int j = 0; j < 8; ++j) { const float f = bf16_at(xr[i], j); part[0][j] += f; part[1][j] += f * f; }
   slab_block_sum<2>(part, red, sums);
 #pragma unroll
-  for (int i = 0; i < FS_PPT; ++i) asm volatile("" : "+v"(xr[i]));   // keep the slab packed (see the backward kernel)
+  for (int i = 0; i < PPT; ++i) asm volatile("" : "+v"(xr[i]));   // keep the slab packed across the reduction
   // group statistics (pre-add folded in analytically)
   const int ng = 64 / a.cg;
   for (int gl = threadIdx.x; gl < ng; gl += blockDim.x) {
@@ -439,45 +491,88 @@ __global__ __launch_bounds__(FS_MAXT) void gn_fwd_fused_kernel(GnArgs a) {
     }
   }
   __syncthreads();
+  // per-channel affine of the slab, once per workgroup
+  for (int cc = threadIdx.x; cc < 64; cc += blockDim.x) {
+    const int cj = c0 + cc;
+    float ka = 0.f, kb = 0.f;
+    if (cj < a.C) {
+      const int gl = cc / a.cg;
+      const float r = s_rstd[gl], mu = s_mean[gl];
+      float sc = 1.f, sh = 0.f;
+      if (a.ss) { sc = 1.f + a.ss[(size_t)b * 2 * a.C + cj]; sh = a.ss[(size_t)b * 2 * a.C + a.C + cj]; }
+      const float pv = a.pre ? a.pre[(size_t)b * a.C + cj] : 0.f;
+      ka = sc * a.gamma[cj] * r;
+      kb = ka * (pv - mu) + sc * a.beta[cj] + sh;
+    }
+    s_ka[cc] = ka;
+    s_kb[cc] = kb;
+  }
+  __syncthreads();
   if (!cok) return;
   float ka[8], kb[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int cj = c + j, gl = (cj - c0) / a.cg;
-    const float r = s_rstd[gl], mu = s_mean[gl];
-    float sc = 1.f, sh = 0.f;
-    if (a.ss) { sc = 1.f + a.ss[(size_t)b * 2 * a.C + cj]; sh = a.ss[(size_t)b * 2 * a.C + a.C + cj]; }
-    const float pv = a.pre ? a.pre[(size_t)b * a.C + cj] : 0.f;
-    ka[j] = sc * a.gamma[cj] * r;
-    kb[j] = ka[j] * (pv - mu) + sc * a.beta[cj] + sh;
-  }
+  for (int j = 0; j < 8; ++j) { ka[j] = s_ka[8 * v + j]; kb[j] = s_kb[8 * v + j]; }
 #pragma unroll
-  for (int i = 0; i < FS_PPT; ++i) {
+  for (int i = 0; i < PPT; ++i) {
     const int p = pl + i * PLN;
     if (p < a.HW) {
       float f[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float u = ka[j] * (float)xr[i][j] + kb[j];
-        f[j] = a.act ? dm_silu(u) : u;
+        const float u = ka[j] * bf16_at(xr[i], j) + kb[j];
+        f[j] = ACT ? dm_silu(u) : u;
       }
       *(bf16x8_t*)(a.y + (base + p) * a.C + c) = dm_pack8(f);
     }
   }
 }
 
-template <int FS_PPT>
-__global__ __launch_bounds__(FS_MAXT) void gn_bwd_fused_kernel(GnArgs a) {
-  __shared__ float red[(FS_MAXT / 64) * 3 * 64];
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  return __builtin_bit_cast(unsigned, bf16x2_t{(bf16_t)lo, (bf16_t)hi});
+}
+
+// Backward. The kernel is as much VALU- as HBM-bound (the SiLU gradient costs an exponential and a reciprocal per
+// element, and a one-workgroup-per-CU kernel cannot hide arithmetic under its own loads), so:
+//  - all arithmetic runs on PAIRS of channels (the two bf16 of a 32-bit word) as 2-wide float vectors, which the
+//    compiler maps to the packed v_pk_* instructions: half the instruction count;
+//  - du = dy * silu'(u) is computed ONCE, in the first pass (fp32, and summed in fp32), then rounded to bf16 into the
+//    registers that held dy; the second pass reads it back instead of evaluating the SiLU gradient again. dx thus
+//    carries one extra bf16 rounding of one of its two terms (it is itself stored as bf16).
+// Register budget: the slab (x and dy, 8 * PPT registers) plus per-channel state; the 8 channels of a thread are
+// processed as two halves of 4 so that only 4 channels' constants are live at a time.
+__device__ __forceinline__ f32x2_t bf16_pair(unsigned w) {
+  return f32x2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+}
+__device__ __forceinline__ unsigned pack_pair(f32x2_t v) { return pack_bf16x2(v[0], v[1]); }
+__device__ __forceinline__ f32x2_t silu_grad_pair(f32x2_t u) {
+  const f32x2_t e = {__expf(-u[0]), __expf(-u[1])};
+  const f32x2_t d = e + 1.0f;
+  const f32x2_t sg = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  return sg * (u * (1.0f - sg) + 1.0f);
+}
+
+template <int PPT, int MAXT, bool ACT, bool EXTRA>
+__global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
+  __shared__ float red[(MAXT / 64) * 3 * 64];
   __shared__ float sums[3 * 64];
-  __shared__ float s_A[64], s_B[64];
+  __shared__ float s_A[64], s_B[64];       // per group of the slab
+  __shared__ __attribute__((aligned(16))) float s_k[4][64];   // per channel: xhat = xa * x + xb, u = ua * x + ub
+  __shared__ __attribute__((aligned(16))) float s_AB[2][64];  // per channel: A and B of its group
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int v = threadIdx.x & 7, pl = threadIdx.x >> 3, PLN = blockDim.x >> 3;
   const int c = c0 + 8 * v;
   const bool cok = c < a.C;
   const size_t base = (size_t)b * a.HW;
-  // per-channel constants in LDS (the slab itself takes up to 128 registers): xhat = xa * x + xb, u = ua * x + ub (ua = sc * gamma * r)
-  __shared__ float s_k[4][64];
+  u32x4_t xr[PPT], dr[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int p = pl + i * PLN;
+    const bool ok = cok && p < a.HW;
+    xr[i] = load_slab_x(a, base, p, c, cok);
+    const u32x4_t d = *(const u32x4_t*)(a.dy + (base + (ok ? p : 0)) * a.C + (cok ? c : 0));
+    dr[i] = ok ? d : u32x4_t{0, 0, 0, 0};
+  }
   for (int cc = threadIdx.x; cc < 64; cc += blockDim.x) {
     const int cj = c0 + cc;
     float kxa = 0.f, kxb = 0.f, kua = 0.f, kub = 0.f;
@@ -494,53 +589,43 @@ __global__ __launch_bounds__(FS_MAXT) void gn_bwd_fused_kernel(GnArgs a) {
     }
     s_k[0][cc] = kxa; s_k[1][cc] = kxb; s_k[2][cc] = kua; s_k[3][cc] = kub;
   }
-  const float* xa = &s_k[0][8 * v];
-  const float* xb = &s_k[1][8 * v];
-  const float* ua = &s_k[2][8 * v];
-  const float* ub = &s_k[3][8 * v];
-  // x stays in registers; dy is parked in LDS between the two passes (each thread reads back only what it wrote);
-  // dynamic LDS: FS_PPT * blockDim.x 16-byte slots, so small samples keep several workgroups per CU
-  extern __shared__ __attribute__((aligned(16))) char s_dyn[];
-  bf16x8_t* s_dy = (bf16x8_t*)s_dyn;
-  bf16x8_t xr[FS_PPT];
-  {
-    bf16x8_t dr[FS_PPT];
+  __syncthreads();   // constants visible
 #pragma unroll
-    for (int i = 0; i < FS_PPT; ++i) {
-      const int p = pl + i * PLN;
-      if (cok && p < a.HW) {
-        xr[i] = load_x(a, base + p, c);
-        dr[i] = *(const bf16x8_t*)(a.dy + (base + p) * a.C + c);
-      } else {
-        xr[i] = dr[i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int h = 0; h < 2; ++h) {
+    const f32x4_t xa = *(const f32x4_t*)&s_k[0][8 * v + 4 * h], xb = *(const f32x4_t*)&s_k[1][8 * v + 4 * h];
+    const f32x4_t ua = *(const f32x4_t*)&s_k[2][8 * v + 4 * h], ub = *(const f32x4_t*)&s_k[3][8 * v + 4 * h];
+    f32x2_t p0[2] = {{0.f, 0.f}, {0.f, 0.f}}, p1[2] = {{0.f, 0.f}, {0.f, 0.f}}, p2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float live = pl + i * PLN < a.HW ? 1.f : 0.f;   // xhat of a lane beyond the image must not be summed
+      // an opaque copy of the pixel's words: the unpacking then cannot be hoisted above this point, so the compiler
+      // works through the slab one pixel at a time instead of widening all of it to floats first
+      unsigned xw[2] = {xr[i][2 * h], xr[i][2 * h + 1]}, dw[2] = {dr[i][2 * h], dr[i][2 * h + 1]};
+      asm volatile("" : "+v"(xw[0]), "+v"(xw[1]), "+v"(dw[0]), "+v"(dw[1]));
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x2_t kxa = {xa[2 * q], xa[2 * q + 1]}, kxb = {xb[2 * q], xb[2 * q + 1]};
+        const f32x2_t xv = bf16_pair(xw[q]), dv = bf16_pair(dw[q]);
+        const f32x2_t xh = kxa * xv + kxb;
+        f32x2_t du = dv;
+        if (ACT) {
+          const f32x2_t kua = {ua[2 * q], ua[2 * q + 1]}, kub = {ub[2 * q], ub[2 * q + 1]};
+          du = dv * silu_grad_pair(kua * xv + kub);
+        }
+        p0[q] += du;
+        p1[q] += du * xh;
+        p2[q] += xh * live;
+        if (ACT) dr[i][2 * h + q] = pack_pair(du);   // dy is consumed: its register takes du for the second pass
       }
     }
-#pragma unroll
-    for (int i = 0; i < FS_PPT; ++i) s_dy[i * blockDim.x + threadIdx.x] = dr[i];
+    float ph[3][4] = {{p0[0][0], p0[0][1], p0[1][0], p0[1][1]}, {p1[0][0], p1[0][1], p1[1][0], p1[1][1]},
+                      {p2[0][0], p2[0][1], p2[1][0], p2[1][1]}};
+    slab_half_to_lds<3>(ph, red, h);
   }
-  __syncthreads();   // constants visible
-  float part[3][8];
+  slab_sum_finish<3>(red, sums);
+  // make the slab opaque here: otherwise the compiler keeps per-element values of the first pass alive for the second
 #pragma unroll
-  for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = part[2][j] = 0.f;
-#pragma unroll
-  for (int i = 0; i < FS_PPT; ++i) {
-    const bool pok = pl + i * PLN < a.HW;
-    const bf16x8_t dri = s_dy[i * blockDim.x + threadIdx.x];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xv = (float)xr[i][j];
-      const float xh = xa[j] * xv + xb[j];
-      const float du = a.act ? (float)dri[j] * dm_silu_grad(ua[j] * xv + ub[j]) : (float)dri[j];
-      part[0][j] += du;
-      part[1][j] += du * xh;
-      part[2][j] += pok ? xh : 0.f;
-    }
-  }
-  slab_block_sum<3>(part, red, sums);
-  // keep the slab PACKED across the reduction: without this the compiler carries the unpacked floats of the first
-  // pass (128 registers) into the second and spills
-#pragma unroll
-  for (int i = 0; i < FS_PPT; ++i) asm volatile("" : "+v"(xr[i]));
+  for (int i = 0; i < PPT; ++i) asm volatile("" : "+v"(xr[i]), "+v"(dr[i]));
   const float inv_n = 1.0f / (float)(a.cg * a.HW);
   const int ng = 64 / a.cg;
   for (int gl = threadIdx.x; gl < ng; gl += blockDim.x) {
@@ -557,9 +642,11 @@ __global__ __launch_bounds__(FS_MAXT) void gn_bwd_fused_kernel(GnArgs a) {
     s_B[gl] = Bv * inv_n;
   }
   __syncthreads();
-  // parameter-side gradients of this slab's channels
+  // parameter-side gradients of this slab's channels; A and B per channel for the second pass
   for (int cc = threadIdx.x; cc < 64; cc += blockDim.x) {
-    const int cj = c0 + cc;
+    const int cj = c0 + cc, gl = cc / a.cg;
+    s_AB[0][cc] = s_A[gl];
+    s_AB[1][cc] = s_B[gl];
     if (cj < a.C) {
       const float av = sums[cc], bv = sums[64 + cc], xs = sums[128 + cc];
       const float sc = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + cj] : 1.f;
@@ -571,7 +658,7 @@ __global__ __launch_bounds__(FS_MAXT) void gn_bwd_fused_kernel(GnArgs a) {
         a.dss[(size_t)b * 2 * a.C + a.C + cj] = av;
       }
       if (a.dpre || a.want_dup) {
-        const int gl = cc / a.cg, g = cj / a.cg;
+        const int g = cj / a.cg;
         const float r = a.rstd[(size_t)b * a.G + g];
         const float dxsum = r * (sc * a.gamma[cj] * av - (float)a.HW * s_A[gl] - s_B[gl] * xs);
         if (a.dpre) a.dpre[(size_t)b * a.C + cj] = dxsum;
@@ -579,42 +666,78 @@ __global__ __launch_bounds__(FS_MAXT) void gn_bwd_fused_kernel(GnArgs a) {
       }
     }
   }
+  __syncthreads();
   if (!cok) return;
-  float Ag[8], Bg[8];
+  // second pass: dx = ua * du - xa * (A + xhat * B) (+ dextra), pixel by pixel with all 8 channels' constants live
+  // (no accumulators are left to hold), stored straight from the registers
+  f32x4_t xa[2], xb[2], ua[2], Ag[2], Bg[2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { const int gl = (c + j - c0) / a.cg; Ag[j] = s_A[gl]; Bg[j] = s_B[gl]; }
+  for (int h = 0; h < 2; ++h) {
+    xa[h] = *(const f32x4_t*)&s_k[0][8 * v + 4 * h]; xb[h] = *(const f32x4_t*)&s_k[1][8 * v + 4 * h];
+    ua[h] = *(const f32x4_t*)&s_k[2][8 * v + 4 * h];
+    Ag[h] = *(const f32x4_t*)&s_AB[0][8 * v + 4 * h]; Bg[h] = *(const f32x4_t*)&s_AB[1][8 * v + 4 * h];
+  }
+  bf16_t* const dxb = c < a.C1 ? a.dx1 + base * a.C1 + c : a.dx2 + base * a.C2 + (c - a.C1);
+  const int dxs = c < a.C1 ? a.C1 : a.C2;
 #pragma unroll
-  for (int i = 0; i < FS_PPT; ++i) {
-    const int p = pl + i * PLN;
-    if (p < a.HW) {
-      const size_t o = (base + p) * a.C + c;
-      float f[8], e[8];
-      if (a.dextra) dm_unpack8(*(const bf16x8_t*)(a.dextra + o), e);
-      const bf16x8_t dri = s_dy[i * blockDim.x + threadIdx.x];
+  for (int i = 0; i < PPT; ++i) {
+    int p = pl + i * PLN;
+    u32x4_t xw = xr[i], dw = dr[i];
+    // opaque: unpacking and address arithmetic stay with their pixel instead of being hoisted for the whole slab
+    asm volatile("" : "+v"(xw), "+v"(dw), "+v"(p));
+    u32x4_t ew = {0, 0, 0, 0};
+    if (EXTRA) ew = *(const u32x4_t*)(a.dextra + (base + min(p, a.HW - 1)) * a.C + c);
+    u32x4_t ow;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float xv = (float)xr[i][j];
-        const float xh = xa[j] * xv + xb[j];
-        const float du = a.act ? (float)dri[j] * dm_silu_grad(ua[j] * xv + ub[j]) : (float)dri[j];
-        const float dxv = ua[j] * du - xa[j] * (Ag[j] + xh * Bg[j]);
-        f[j] = a.dextra ? dxv + e[j] : dxv;
-      }
-      const bf16x8_t ov = dm_pack8(f);
-      if (c < a.C1) *(bf16x8_t*)(a.dx1 + (base + p) * a.C1 + c) = ov;
-      else *(bf16x8_t*)(a.dx2 + (base + p) * a.C2 + (c - a.C1)) = ov;
+    for (int w = 0; w < 4; ++w) {
+      const int h = w >> 1, q = w & 1;
+      const f32x2_t kxa = {xa[h][2 * q], xa[h][2 * q + 1]}, kxb = {xb[h][2 * q], xb[h][2 * q + 1]};
+      const f32x2_t kua = {ua[h][2 * q], ua[h][2 * q + 1]};
+      const f32x2_t kA = {Ag[h][2 * q], Ag[h][2 * q + 1]}, kB = {Bg[h][2 * q], Bg[h][2 * q + 1]};
+      const f32x2_t xh = kxa * bf16_pair(xw[w]) + kxb;
+      f32x2_t r = kua * bf16_pair(dw[w]) - kxa * (kA + xh * kB);
+      if (EXTRA) r += bf16_pair(ew[w]);
+      ow[w] = pack_pair(r);
     }
+    if (p < a.HW) *(u32x4_t*)(dxb + (size_t)p * dxs) = ow;
   }
 }
 
-// the single-pass kernels cover this descriptor? (backward: 8 pixels per thread only - with 16 the slab no longer
-// fits the register file beside the arithmetic)
-bool fused_ok(const GnArgs& a, bool backward) {
-  return g_dm_gn_fused && a.cg <= 64 && 64 % a.cg == 0 && a.HW <= FS_MAXT / 8 * (backward ? 8 : 16);
+// the single-pass kernels cover this descriptor?
+bool fused_ok(const GnArgs& a) {
+  return g_dm_gn_fused && a.cg <= 64 && 64 % a.cg == 0 && a.HW <= 1024;
 }
-int fused_ppt(const GnArgs& a) { return a.HW > FS_MAXT / 8 * 8 ? 16 : 8; }
+// pixels per thread: the smallest of 1, 2, 4, 8 with at most 64 pixel lanes (128 beyond 512 pixels)
+int fused_ppt(const GnArgs& a) {
+  for (int ppt = 1; ppt < 8; ppt *= 2)
+    if (dm_cdiv(a.HW, ppt) <= 64) return ppt;
+  return 8;
+}
 int fused_threads(const GnArgs& a) {   // one thread per (pixel lane, 8-channel vector)
   const int lanes = dm_cdiv(a.HW, fused_ppt(a));
   return dm_cdiv(lanes * 8, 64) * 64;
+}
+
+template <bool BWD>
+void launch_fused(const GnArgs& a, hipStream_t st) {
+  const dim3 grid(dm_cdiv(a.C, 64), a.B), block(fused_threads(a));
+  const int ppt = fused_ppt(a);
+#define DM_GN_LAUNCH(P, T)                                                                                   \
+  do {                                                                                                       \
+    if (BWD) {                                                                                               \
+      if (a.act && a.dextra) hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, true, true>), grid, block, 0, st, a);   \
+      else if (a.act) hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, true, false>), grid, block, 0, st, a);   \
+      else if (a.dextra) hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, false, true>), grid, block, 0, st, a); \
+      else hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, false, false>), grid, block, 0, st, a);             \
+    } else if (a.act) hipLaunchKernelGGL((gn_fwd_fused_kernel<P, T, true>), grid, block, 0, st, a);          \
+    else hipLaunchKernelGGL((gn_fwd_fused_kernel<P, T, false>), grid, block, 0, st, a);                      \
+  } while (0)
+  if (ppt == 1) DM_GN_LAUNCH(1, 512);
+  else if (ppt == 2) DM_GN_LAUNCH(2, 512);
+  else if (ppt == 4) DM_GN_LAUNCH(4, 512);
+  else if (a.HW <= 512) DM_GN_LAUNCH(8, 512);
+  else DM_GN_LAUNCH(8, 1024);
+#undef DM_GN_LAUNCH
 }
 
 int check_desc(const dm_gn_desc* d, const char* who) {
@@ -694,9 +817,8 @@ extern "C" int dm_groupnorm_act_fwd(const dm_gn_desc* d, const void* x1, const v
   a.y = (bf16_t*)y; a.mean = mean; a.rstd = rstd; a.ws = ws;
   fill(a, d);
   hipStream_t st = (hipStream_t)stream;
-  if (fused_ok(a, false)) {
-    if (fused_ppt(a) == 16) hipLaunchKernelGGL(gn_fwd_fused_kernel<16>, dim3(dm_cdiv(a.C, 64), a.B), dim3(fused_threads(a)), 0, st, a);
-    else hipLaunchKernelGGL(gn_fwd_fused_kernel<8>, dim3(dm_cdiv(a.C, 64), a.B), dim3(fused_threads(a)), 0, st, a);
+  if (fused_ok(a)) {
+    launch_fused<false>(a, st);
     DM_CHECK_LAUNCH();
     return DM_OK;
   }
@@ -749,8 +871,8 @@ extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const v
   a.dss = dscale_shift; a.dpre = dpre_add; a.pp = param_partials; a.want_dup = want_upstream_bias; a.ws = ws;
   fill(a, d);
   hipStream_t st = (hipStream_t)stream;
-  if (fused_ok(a, true)) {
-    hipLaunchKernelGGL(gn_bwd_fused_kernel<8>, dim3(dm_cdiv(a.C, 64), a.B), dim3(fused_threads(a)), 8 * fused_threads(a) * 16, st, a);
+  if (fused_ok(a)) {
+    launch_fused<true>(a, st);
     DM_CHECK_LAUNCH();
     return DM_OK;
   }
