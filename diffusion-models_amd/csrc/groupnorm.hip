@@ -53,6 +53,7 @@ struct GnArgs {
   int want_dup; // the third term (bias gradient of the convolution that produced x) is asked for
   float* ws;
   int B, HW, C1, C2, C, G, cg, act, pch;
+  int sw;   // channels per workgroup of the single-pass kernels: whole groups, a multiple of 8, at most 64 (0: none)
   float eps;
 };
 
@@ -346,8 +347,10 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(GnArgs a) {
 }
 
 // ============================================================================================================
-// Single-pass kernels for the common case (channels per group divide 64, at most 1024 pixels per sample).
-// One workgroup = (sample b, 64 channels): it holds that slab of x (and dy) IN REGISTERS as packed bf16 - thread =
+// Single-pass kernels for the common case (at most 1024 pixels per sample; whole groups fit a slab of at most 64
+// channels that is a multiple of 8: 64 when the group size divides 64, 48 for groups of 6, 12 or 24 channels - the
+// concatenated inputs of the up path - with the last two of a pixel's eight vector lanes idle).
+// One workgroup = (sample b, one slab of channels): it holds that slab of x (and dy) IN REGISTERS as packed bf16 - thread =
 // (8-channel vector, pixel lane), PPT pixels per thread - so every tensor is read from memory exactly once and the
 // sums never leave the CU: forward 4 B/element instead of 6, backward 6 (+2 with a residual gradient) instead of 10.
 // PPT is the smallest of 1, 2, 4, 8 that brings the pixel lanes down to 64 (512 threads; 128 lanes = 1024 threads for
@@ -445,10 +448,10 @@ __global__ __launch_bounds__(MAXT) void gn_fwd_fused_kernel(GnArgs a) {
   __shared__ float sums[2 * 64];
   __shared__ float s_mean[64], s_rstd[64];   // per group of the slab
   __shared__ float s_ka[64], s_kb[64];
-  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int b = blockIdx.y, c0 = blockIdx.x * a.sw;
   const int v = threadIdx.x & 7, pl = threadIdx.x >> 3, PLN = blockDim.x >> 3;
   const int c = c0 + 8 * v;
-  const bool cok = c < a.C;
+  const bool cok = 8 * v < a.sw && c < a.C;   // (slabs narrower than 64 channels leave their last vector lanes idle)
   const size_t base = (size_t)b * a.HW;
   u32x4_t xr[PPT];   // packed bf16 pairs: 4 registers per 8 channels of a pixel
   float part[2][8];
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(MAXT) void gn_fwd_fused_kernel(GnArgs a) {
 #pragma unroll
   for (int i = 0; i < PPT; ++i) asm volatile("" : "+v"(xr[i]));   // keep the slab packed across the reduction
   // group statistics (pre-add folded in analytically)
-  const int ng = 64 / a.cg;
+  const int ng = a.sw / a.cg;
   for (int gl = threadIdx.x; gl < ng; gl += blockDim.x) {
     const int g = c0 / a.cg + gl;
     if (g < a.G) {
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(MAXT) void gn_fwd_fused_kernel(GnArgs a) {
   for (int cc = threadIdx.x; cc < 64; cc += blockDim.x) {
     const int cj = c0 + cc;
     float ka = 0.f, kb = 0.f;
-    if (cj < a.C) {
+    if (cc < a.sw && cj < a.C) {
       const int gl = cc / a.cg;
       const float r = s_rstd[gl], mu = s_mean[gl];
       float sc = 1.f, sh = 0.f;
@@ -559,10 +562,10 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
   __shared__ float s_A[64], s_B[64];       // per group of the slab
   __shared__ __attribute__((aligned(16))) float s_k[4][64];   // per channel: xhat = xa * x + xb, u = ua * x + ub
   __shared__ __attribute__((aligned(16))) float s_AB[2][64];  // per channel: A and B of its group
-  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int b = blockIdx.y, c0 = blockIdx.x * a.sw;
   const int v = threadIdx.x & 7, pl = threadIdx.x >> 3, PLN = blockDim.x >> 3;
   const int c = c0 + 8 * v;
-  const bool cok = c < a.C;
+  const bool cok = 8 * v < a.sw && c < a.C;
   const size_t base = (size_t)b * a.HW;
   u32x4_t xr[PPT], dr[PPT];
 #pragma unroll
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
   for (int cc = threadIdx.x; cc < 64; cc += blockDim.x) {
     const int cj = c0 + cc;
     float kxa = 0.f, kxb = 0.f, kua = 0.f, kub = 0.f;
-    if (cj < a.C) {
+    if (cc < a.sw && cj < a.C) {
       const int g = cj / a.cg;
       const float r = a.rstd[(size_t)b * a.G + g], mu = a.mean[(size_t)b * a.G + g];
       const float pv = a.pre ? a.pre[(size_t)b * a.C + cj] : 0.f;
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
 #pragma unroll
   for (int i = 0; i < PPT; ++i) asm volatile("" : "+v"(xr[i]), "+v"(dr[i]));
   const float inv_n = 1.0f / (float)(a.cg * a.HW);
-  const int ng = 64 / a.cg;
+  const int ng = a.sw / a.cg;
   for (int gl = threadIdx.x; gl < ng; gl += blockDim.x) {
     float A = 0.f, Bv = 0.f;
     for (int j = 0; j < a.cg; ++j) {
@@ -644,10 +647,10 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
   __syncthreads();
   // parameter-side gradients of this slab's channels; A and B per channel for the second pass
   for (int cc = threadIdx.x; cc < 64; cc += blockDim.x) {
-    const int cj = c0 + cc, gl = cc / a.cg;
+    const int cj = c0 + cc, gl = cc < a.sw ? cc / a.cg : 0;
     s_AB[0][cc] = s_A[gl];
     s_AB[1][cc] = s_B[gl];
-    if (cj < a.C) {
+    if (cc < a.sw && cj < a.C) {
       const float av = sums[cc], bv = sums[64 + cc], xs = sums[128 + cc];
       const float sc = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + cj] : 1.f;
       float* pp = a.pp + (size_t)b * 3 * a.C;
@@ -704,8 +707,14 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
 }
 
 // the single-pass kernels cover this descriptor?
-bool fused_ok(const GnArgs& a) {
-  return g_dm_gn_fused && a.cg <= 64 && 64 % a.cg == 0 && a.HW <= 1024;
+// (slabs narrower than 64 channels only up to 512 pixels: at 1024 pixels their idle lanes and 96-byte rows measured
+// slower than the two-sweep kernels, 142 against 97 us on a 384-channel 32x32 layer at batch 128)
+bool fused_ok(const GnArgs& a) { return g_dm_gn_fused && a.sw > 0 && a.HW <= (a.sw == 64 ? 1024 : 512); }
+// slab width: the largest run of whole groups that is a multiple of 8 channels and at most 64 (0 if there is none)
+int slab_width(int cg) {
+  int l = cg;
+  while (l % 8) l += cg;   // lcm(cg, 8)
+  return l <= 64 ? 64 / l * l : 0;
 }
 // pixels per thread: the smallest of 1, 2, 4, 8 with at most 64 pixel lanes (128 beyond 512 pixels)
 int fused_ppt(const GnArgs& a) {
@@ -720,7 +729,7 @@ int fused_threads(const GnArgs& a) {   // one thread per (pixel lane, 8-channel 
 
 template <bool BWD>
 void launch_fused(const GnArgs& a, hipStream_t st) {
-  const dim3 grid(dm_cdiv(a.C, 64), a.B), block(fused_threads(a));
+  const dim3 grid(dm_cdiv(a.C, a.sw), a.B), block(fused_threads(a));
   const int ppt = fused_ppt(a);
 #define DM_GN_LAUNCH(P, T)                                                                                   \
   do {                                                                                                       \
@@ -765,6 +774,7 @@ void fill(GnArgs& a, const dm_gn_desc* d) {
   a.B = d->B; a.HW = d->HW; a.C1 = d->C1; a.C2 = d->C2; a.C = d->C1 + d->C2; a.G = d->G; a.cg = a.C / a.G;
   a.act = d->act; a.eps = d->eps;
   a.pch = pick_chunk(a.B, a.HW, a.C);
+  a.sw = slab_width(a.cg);
 }
 
 }  // namespace

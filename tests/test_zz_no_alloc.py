@@ -55,9 +55,9 @@ def _case(B, C1, C2, H, W, ss, seed):
 def test_noalloc_groupnorm_equals_workspace_form_two_calls_in_a_row():
     from dm_hip import check, lib
     check(lib.dm_noalloc_init())
-    # both shapes take the two-sweep kernels, which are the ones that use the scratch (12 channels per group do not
-    # divide a 64-channel slab; 1600 pixels exceed the single-pass kernels); the second call is smaller
-    _case(24, 256, 128, 16, 16, True, 1)
+    # both shapes take the two-sweep kernels, which are the ones that use the scratch (more than 1024 pixels per
+    # sample exceed the single-pass kernels); the second call is smaller
+    _case(6, 256, 128, 36, 36, True, 1)
     _case(3, 64, 0, 40, 40, False, 2)
     # single-pass shape (scratch unused) still goes through the same entry point
     _case(2, 128, 0, 8, 8, True, 3)
