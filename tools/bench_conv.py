@@ -103,9 +103,9 @@ def main():
         if "d" in which:
             t_d = timeit(lambda: check(lib.dm_conv2d_igemm(ctypes.byref(dt), p(dy), None, p(wt), None, None, p(dx), st)), warm=[dy])
         if "w" in which:
-            wsb = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(d)) if os.environ.get("DM_BENCH_WS", "1") == "1" else 0
+            wsb = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(d))
             ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
-            t_w = timeit(lambda: check(lib.dm_conv2d_wgrad_ws(ctypes.byref(d), p(x1), p(x2), p(dy), p(dw), p(ws) if wsb else None, wsb, st)), warm=[dy])
+            t_w = timeit(lambda: check(lib.dm_conv2d_wgrad(ctypes.byref(d), p(x1), p(x2), p(dy), p(dw), p(ws), wsb, st)), warm=[dy])
         for key, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
             tot[key][0] += flops
             tot[key][1] += t
