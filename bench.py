@@ -68,8 +68,35 @@ def synthetic_batch(cfg, rank, device, batch):
     return x.to(device), cls.to(device)
 
 
-class ConvTimer:
-    """Wraps the conv entry points of the C ABI with HIP events on the launching stream."""
+HBM_PEAK_TBS = 8.0
+
+
+def _gn_elems(d):
+    return d.B * d.HW * (d.C1 + d.C2)
+
+
+# entry point -> (kernel family label, algorithmic bytes of one call from its ctypes arguments): every tensor the
+# operator has to touch, once (bf16 activations 2 B, fp32 4 B); descriptors arrive as ctypes byref objects
+HBM_OPS = {
+    "dm_groupnorm_act_fwd": ("gn_fwd (GroupNorm+scale/shift+SiLU forward)", lambda a: 4.0 * _gn_elems(a[0]._obj)),
+    "dm_groupnorm_act_bwd": ("gn_bwd (GroupNorm+SiLU backward)",
+                             lambda a: (8.0 if a[10] else 6.0) * _gn_elems(a[0]._obj)),
+    "dm_colsum_bf16": ("colsum (conv bias gradient)", lambda a: 2.0 * a[2] * a[3]),
+    "dm_colsum_bf16_dual": ("colsum (conv bias gradient)", lambda a: 2.0 * a[3] * a[4]),
+    "dm_grad_norm": ("sumsq (global gradient norm)", lambda a: 4.0 * a[1]),
+    "dm_adamw_ema_step": ("adamw_ema (clip+AdamW+EMA+bf16 mirror)", lambda a: 38.0 * a[8]),
+    "dm_diffuse": ("diffuse (noising)", lambda a: 12.0 * a[6] * a[7]),
+    "dm_mse_loss_fwd": ("mse_fwd (loss)", lambda a: (12.0 if a[1] else 8.0) * a[5]),
+    "dm_mse_loss_bwd": ("mse_bwd (loss gradient)", lambda a: (16.0 if a[1] else 12.0) * a[5]),
+    "dm_sampler_step": ("sampler_step (DDPM/DDIM/Euler update)", lambda a: (16.0 if a[2] else 12.0) * a[10]),
+}
+CONV_OPS = ("dm_conv2d_igemm", "dm_conv2d_wgrad")
+
+
+class AbiTimer:
+    """Wraps entry points of the C ABI with HIP events on the launching stream (torch's current stream: the timed
+    passes run with the side streams off). Convolutions are recorded with their flops, the HBM-bound operators with
+    their algorithmic bytes."""
 
     def __init__(self):
         from dm_hip import lib
@@ -77,26 +104,29 @@ class ConvTimer:
         self.records = []
 
     def __enter__(self):
-        self._orig = {n: getattr(self.lib, n) for n in ("dm_conv2d_igemm", "dm_conv2d_wgrad")}
+        self._orig = {n: getattr(self.lib, n) for n in CONV_OPS + tuple(HBM_OPS)}
         for name, fn in self._orig.items():
             setattr(self.lib, name, self._wrap(name, fn))
         return self
 
     def _wrap(self, name, fn):
-        def call(desc, *args):
-            d = desc._obj
-            m = d.B * d.Ho * d.Wo
-            flops = 2.0 * m * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
-            # algorithmic bytes: every operand once (input, weights, output, residual of the fused epilogue)
-            nbytes = 2.0 * (d.B * d.Hs * d.Ws * (d.C1 + d.C2) + d.Cout * d.KH * d.KW * (d.C1 + d.C2) + m * d.Cout)
-            if name == "dm_conv2d_igemm" and len(args) > 4 and args[4]:
-                nbytes += 2.0 * m * d.Cout
+        def call(*args):
+            if name in CONV_OPS:
+                d = args[0]._obj
+                m = d.B * d.Ho * d.Wo
+                work = 2.0 * m * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
+                # algorithmic bytes: every operand once (input, weights, output, residual of the fused epilogue)
+                nbytes = 2.0 * (d.B * d.Hs * d.Ws * (d.C1 + d.C2) + d.Cout * d.KH * d.KW * (d.C1 + d.C2) + m * d.Cout)
+                if name == "dm_conv2d_igemm" and args[5]:
+                    nbytes += 2.0 * m * d.Cout
+                shape = (m, d.Cout, d.C1 + d.C2, d.KH, d.stride, d.ups, d.transposed)
+            else:
+                work, nbytes, shape = 0.0, float(HBM_OPS[name][1](args)), None
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            rc = fn(desc, *args)
+            rc = fn(*args)
             e1.record()
-            # (the weight gradient's time includes its slab-sum kernel)
-            self.records.append((name, flops, e0, e1, nbytes, (d.B * d.Ho * d.Wo, d.Cout, d.C1 + d.C2, d.KH, d.stride, d.ups, d.transposed)))
+            self.records.append((name, work, e0, e1, nbytes, shape))
             return rc
         return call
 
@@ -109,16 +139,36 @@ class ConvTimer:
         out = {}
         dump = os.environ.get("DM_BENCH_DUMP_CONVS")
         for name, flops, e0, e1, nbytes, shape in self.records:
-            if dump:
-                ms = e0.elapsed_time(e1)
+            ms = e0.elapsed_time(e1)
+            if dump and shape:
                 sys.stderr.write(f"[conv] {name[11:]:6s} M={shape[0]:6d} N={shape[1]:4d} C={shape[2]:4d} k={shape[3]} s={shape[4]} "
                                  f"ups={shape[5]} T={shape[6]} {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF\n")
             s = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
             s["launches"] += 1
             s["flops"] += flops
             s["bytes"] += nbytes
-            s["ms"] += e0.elapsed_time(e1)
+            s["ms"] += ms
         return out
+
+
+def hbm_rows(summary):
+    """One row per HBM-bound operator family: algorithmic bytes and HIP-event time per launch -> TB/s against 8 TB/s."""
+    fam = {}
+    for name, s in summary.items():
+        if name not in HBM_OPS:
+            continue
+        f = fam.setdefault(HBM_OPS[name][0], {"launches": 0, "bytes": 0.0, "ms": 0.0})
+        for k in f:
+            f[k] += s[k]
+    rows = []
+    for label, f in fam.items():
+        if f["ms"] <= 0:
+            continue
+        tbs = f["bytes"] / (f["ms"] * 1e-3) / 1e12
+        rows.append({"kernel": label, "launches": f["launches"], "bytes_per_launch": round(f["bytes"] / f["launches"]),
+                     "us": round(f["ms"] * 1e3 / f["launches"], 2), "tb_s": round(tbs, 3),
+                     "frac": round(tbs / HBM_PEAK_TBS, 4)})
+    return rows
 
 
 def cpu_baseline(cfg, budget_s=20.0, batch=16):
@@ -159,33 +209,34 @@ def cpu_baseline(cfg, budget_s=20.0, batch=16):
                                       f"{batch} (fp32, torch CPU primitives) after 1 warm-up step"}
 
 
-def bench_sampling(args, cfg, device, rank, world):
-    """Sampling throughput: every rank generates --sample-batch images per step of this bench with the config's
-    sampler (one "step" = one whole n-step sampling loop on one batch), UNet forward replayed from a HIP graph."""
+def sampling_row(model, cfg, device, rank, world, config_name, sampler_type=None, n_steps=None, batch=256,
+                 repeats=1, warmup=1, use_graph=True):
+    """Sampling throughput of one (sampler, n_steps) setting: every rank runs the whole n-step loop on `batch` images
+    (train.py:476-504: get_pred_fn + sampler.sample + clip), UNet forward replayed from a HIP graph. Returns a dict
+    (on every rank; times are the max over ranks)."""
     from diffusion.sampler import get_sampler
     from diffusion.scheduler import get_scheduler
     from harness.generate import GraphedPredictor
-    from modeling import get_model
-    torch.manual_seed(42)
-    model = get_model(cfg["model_type"], **cfg["model_cfg"]).to(device).eval()
     sched = get_scheduler(cfg["scheduler_type"], **cfg["scheduler_cfg"])
-    scfg = dict(cfg["sampler_cfg"])
-    if args.sample_steps is not None:
-        scfg["n_steps"] = args.sample_steps
+    stype = sampler_type or cfg["sampler_type"]
+    scfg = dict(cfg["sampler_cfg"]) if stype == cfg["sampler_type"] else {}
+    scfg["n_steps"] = n_steps or scfg.get("n_steps", 50)
     scfg["pbar"] = False
-    sampler = get_sampler(cfg["sampler_type"], **scfg)
-    B = args.sample_batch
+    sampler = get_sampler(stype, **scfg)
     g = torch.Generator().manual_seed(42 + rank)
     c = cfg["model_cfg"]["in_channels"]
     hw = 28 if cfg["dataset"] == "mnist" else 32
-    z = torch.randn(B, c, hw, hw, generator=g).to(device)
-    cls = torch.randint(0, 10, (B,), generator=g).to(device)
+    z = torch.randn(batch, c, hw, hw, generator=g).to(device)
+    cls = torch.randint(0, 10, (batch,), generator=g).to(device)
+    was_training = model.training
+    model.eval()
     pred = model.get_pred_fn(cond=cls, guidance_scale=cfg.get("guidance_scale", 1.0))
-    if not args.no_graph:
+    if use_graph:
         pred = GraphedPredictor(pred)
 
     def run():
-        return torch.clip(sampler.sample(z, sched, pred), -1, 1)
+        with torch.no_grad():
+            return torch.clip(sampler.sample(z.clone(), sched, pred), -1, 1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -193,11 +244,14 @@ def bench_sampling(args, cfg, device, rank, world):
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    if use_graph:   # capture outside the timed region (and warm the first replay)
+        with torch.no_grad():
+            pred(z.clone(), torch.zeros(batch, dtype=torch.int64, device=device))
+    for _ in range(warmup):
         run()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(repeats):
         run()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -205,20 +259,41 @@ def bench_sampling(args, cfg, device, rank, world):
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    if was_training:
+        model.train()
+    per = elapsed / repeats
+    n = scfg["n_steps"]
+    fwd_tflop = FWD_GFLOP_PER_IMG.get(config_name, 0.0) * batch * n / 1e3
+    tf = fwd_tflop / per if fwd_tflop else None
+    return {"sampler": stype, "n_steps": n, "batch_per_gpu": batch, "img_s": round(batch * world / per, 2),
+            "s_per_batch": round(per, 4), "unet_forward_ms": round(per * 1e3 / n, 3),
+            "tflops": round(tf, 1) if tf else None,
+            "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4) if tf else None, "hip_graph": bool(use_graph),
+            "activations": "bf16 (the reference samples in fp32)"}
+
+
+def bench_sampling(args, cfg, device, rank, world):
+    """--mode sample: the sampling loop of the config as the headline line (one "step" = one whole n-step loop)."""
+    from modeling import get_model
+    torch.manual_seed(42)
+    model = get_model(cfg["model_type"], **cfg["model_cfg"]).to(device).eval()
+    row = sampling_row(model, cfg, device, rank, world, args.config, sampler_type=args.sampler,
+                       n_steps=args.sample_steps, batch=args.sample_batch, repeats=args.steps, warmup=args.warmup,
+                       use_graph=not args.no_graph)
     if rank == 0:
-        n_steps = scfg["n_steps"]
-        fwd_tflop = FWD_GFLOP_PER_IMG.get(args.config, 0.0) * B * n_steps / 1e3
-        per = elapsed / args.steps
         print(json.dumps({
-            "metric": f"sample imgs/sec @{n_steps} steps ({cfg['sampler_type']})", "value": round(B * world / per, 2),
+            "metric": f"sample imgs/sec @{row['n_steps']} steps ({row['sampler']})", "value": row["img_s"],
             "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(per * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"arg_json/{args.config}.json sampling loop, {n_steps} sampler steps, batch {B}/GPU",
-                       "parallelism": f"shard{world}", "hip_graph": not args.no_graph},
-            "unet_forward_ms": round(per * 1e3 / n_steps, 3),
-            "step_tflops_achieved": round(fwd_tflop / per, 2) if fwd_tflop else None,
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "ms_per_step": round(row["s_per_batch"] * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"arg_json/{args.config}.json sampling loop, {row['sampler']} {row['n_steps']} steps, "
+                                   f"batch {args.sample_batch}/GPU", "parallelism": f"shard{world}",
+                       "hip_graph": not args.no_graph},
+            "unet_forward_ms": row["unet_forward_ms"], "step_tflops_achieved": row["tflops"],
+            "roofline": {"bound": "mfma", "kernel": "UNet forward (all kernels of one sampler step)",
+                         "achieved": row["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": row["frac"],
+                         "traffic": None},
+            "cpu_baseline": None}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -240,6 +315,9 @@ def main():
                     help="train: the training step (the headline metric); sample: the sampling loop of the config")
     ap.add_argument("--sample-batch", type=int, default=256, help="images per GPU per sampling batch (generation_batch_size)")
     ap.add_argument("--sample-steps", type=int, default=None, help="sampler steps (default: the config's)")
+    ap.add_argument("--sampler", default=None, help="sampler type override for --mode sample (ddpm, ddim, euler)")
+    ap.add_argument("--no-sampling", action="store_true",
+                    help="train mode: skip the sampling rows (config sampler, and DDPM ancestral 1000 steps on VP configs)")
     ap.add_argument("--side-streams", type=int, default=None,
                     help="streams the weight-gradient kernels rotate over beside the main one (0: none; default: the harness's)")
     args = ap.parse_args()
@@ -331,26 +409,52 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = batch * world * args.steps / elapsed
 
-    # dominant-kernel roofline from one instrumented eager step
-    roof = None
+    # dominant-kernel roofline and per-kernel HBM rates from one instrumented eager step (every launch alone on one
+    # stream, HIP events around each entry point)
+    roof, hbm, summ = None, None, {}
     if rank == 0:
-        step.side_wgrad = 0  # time every launch alone on one stream
-        with ConvTimer() as ct:
+        step.side_wgrad = 0
+        with AbiTimer() as ct:
             step.step(x, cls)
-        s = ct.summary()
-        ig, wg = s.get("dm_conv2d_igemm"), s.get("dm_conv2d_wgrad")
+            # the sampler update kernels: three eager steps of each family on a generation-sized batch
+            from diffusion.sampler import get_sampler
+            zz = torch.randn(256, *x.shape[1:], device=device)
+            fake = lambda z_, t_: z_  # noqa: E731  (the update kernel is what is timed here, not the network)
+            if sched.pred_type == "noise":
+                get_sampler("ddim", n_steps=3, pbar=False).sample(zz, sched, fake)
+                get_sampler("ddpm", n_steps=3, pbar=False).sample(zz, sched, fake)
+            else:
+                get_sampler("euler", n_steps=3, pbar=False).sample(zz, sched, fake)
+        summ = ct.summary()
+        ig, wg = summ.get("dm_conv2d_igemm"), summ.get("dm_conv2d_wgrad")
         if ig and ig["ms"] > 0:
             achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + data-gradient launches)",
+            traffic = measured_conv_traffic()
+            roof = {"bound": "mfma",
+                    "kernel": "conv_patch_kernel<128,6> / conv_patch_kernel<64,7> / conv_igemm_kernel<128>: every "
+                              "dm_conv2d_igemm launch of a step (forward + data gradient)",
                     "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                    # HBM-side bytes per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, averaged
-                    # over the same launches), beside the algorithmic bytes per launch of this run
-                    "traffic": measured_conv_traffic(), "traffic_unit": "bytes/launch",
+                    "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_source": "profiles/r01_conv_traffic.json (rocprofv3 --pmc passes of this benchmark: "
+                                      "2 x FETCH_SIZE + WRITE_SIZE; not measured by this run)" if traffic else None,
                     "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["launches"]),
                     "launches_per_step": ig["launches"], "ms_per_step": round(ig["ms"], 3),
-                    "wgrad": {"achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2), "launches_per_step": wg["launches"],
+                    "wgrad": {"kernel": "conv_wgrad3_kernel<4> / conv_wgrad_kernel<..> + their slab-sum kernels",
+                              "achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2),
+                              "frac": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                              "launches_per_step": wg["launches"],
                               "ms_per_step": round(wg["ms"], 3)} if wg and wg["ms"] > 0 else None}
+        hbm = hbm_rows(summ)
+
+    # sampling rows (BASELINE metric: "sample imgs/sec @N steps"): the config's own sampler, and DDPM ancestral
+    # sampling over all 1000 steps where the scheduler is variance preserving
+    sampling = None
+    if not args.no_sampling:
+        sampling = [sampling_row(model, cfg, device, rank, world, args.config, batch=args.sample_batch)]
+        if sched.pred_type == "noise":
+            sampling.append(sampling_row(model, cfg, device, rank, world, args.config, sampler_type="ddpm",
+                                         n_steps=cfg["scheduler_cfg"]["n_steps"], batch=args.sample_batch, warmup=0))
 
     if rank == 0:
         step_tflop = 3 * FWD_GFLOP_PER_IMG.get(args.config, 0.0) * batch / 1e3
@@ -366,6 +470,8 @@ def main():
             "step_tflops_achieved": round(step_tflop / (ms_per_step * 1e-3), 2) if step_tflop else None,
             "step_mfma_frac": round(step_tflop / (ms_per_step * 1e-3) / MFMA_BF16_PEAK_TFLOPS / world, 4) if step_tflop else None,
             "roofline": roof,
+            "hbm": hbm,
+            "sampling": sampling,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, budget_s=args.cpu_budget)
