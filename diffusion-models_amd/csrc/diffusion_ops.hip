@@ -70,23 +70,51 @@ __global__ void mse_bwd_kernel(const float* __restrict__ pred, const float* __re
     dpred[i] = g * (pred[i] - target_of(x, eps, i, mode));
 }
 
+// one element of a sampler update (shared by the by-value and the device-table kernels: identical arithmetic)
+__device__ __forceinline__ float sampler_update(float zi, float p, const float* noise, long i, float c0, float c1, float c2,
+                                                float c3, int mode, int clip, int last) {
+  float r;
+  if (mode == 0) {
+    r = __fmul_rn(c0, __fsub_rn(zi, __fmul_rn(c1, p)));
+    if (noise) r = __fadd_rn(r, __fmul_rn(c2, noise[i]));
+  } else if (mode == 1) {
+    float x0 = __fdiv_rn(__fsub_rn(zi, __fmul_rn(c1, p)), c0);
+    if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    r = last ? x0 : __fadd_rn(__fmul_rn(c2, x0), __fmul_rn(c3, p));
+  } else {
+    r = __fsub_rn(zi, __fmul_rn(c0, p));
+  }
+  return r;
+}
+
+// The update of loop step i = step[0], with the step's four scalars read from a device table: a captured HIP graph
+// can then replay the same launch for every step of a sampling loop. The step's noise is ignored on the last step
+// (the reference draws none there).
+__global__ void sampler_step_dev_kernel(float* __restrict__ z, const float* __restrict__ pred,
+                                        const float* __restrict__ noise, const float* __restrict__ coefs,
+                                        const long long* __restrict__ step, int n_steps, int mode, int clip, long total) {
+  const long long s = step[0];
+  if (s < 0 || s >= n_steps) return;   // replayed more often than the loop has steps: leave z alone
+  const float c0 = coefs[4 * s], c1 = coefs[4 * s + 1], c2 = coefs[4 * s + 2], c3 = coefs[4 * s + 3];
+  const int last = s == n_steps - 1;
+  const float* nz = last ? nullptr : noise;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT)
+    z[i] = sampler_update(z[i], pred[i], nz, i, c0, c1, c2, c3, mode, clip, last);
+}
+// step[0] += 1 and t_out[b] = t_table[step] for the next UNet forward (one workgroup; runs after the update kernel)
+__global__ void sampler_tick_kernel(long long* __restrict__ step, const int64_t* __restrict__ t_table,
+                                    int64_t* __restrict__ t_out, int n_steps, int B) {
+  const long long s = step[0] + 1;
+  const int64_t t = t_table[s < n_steps ? s : n_steps - 1];
+  for (int b = threadIdx.x; b < B; b += blockDim.x) t_out[b] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) step[0] = s;
+}
+
 __global__ void sampler_step_kernel(float* __restrict__ z, const float* __restrict__ pred, const float* __restrict__ noise,
                                     float c0, float c1, float c2, float c3, int mode, int clip, int last, long total) {
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-    const float zi = z[i], p = pred[i];
-    float r;
-    if (mode == 0) {
-      r = __fmul_rn(c0, __fsub_rn(zi, __fmul_rn(c1, p)));
-      if (noise) r = __fadd_rn(r, __fmul_rn(c2, noise[i]));
-    } else if (mode == 1) {
-      float x0 = __fdiv_rn(__fsub_rn(zi, __fmul_rn(c1, p)), c0);
-      if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-      r = last ? x0 : __fadd_rn(__fmul_rn(c2, x0), __fmul_rn(c3, p));
-    } else {
-      r = __fsub_rn(zi, __fmul_rn(c0, p));
-    }
-    z[i] = r;
-  }
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT)
+    z[i] = sampler_update(z[i], pred[i], noise, i, c0, c1, c2, c3, mode, clip, last);
 }
 
 __global__ void cfg_combine_kernel(const float* __restrict__ u, const float* __restrict__ c, float* __restrict__ out,
@@ -144,6 +172,20 @@ extern "C" int dm_sampler_step(float* z, const float* pred, const float* noise, 
   DM_REQUIRE(z && pred && total > 0 && mode >= 0 && mode <= 2, DM_ERR_ARG, "dm_sampler_step: bad argument");
   hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, z, pred, noise, c0, c1,
                      c2, c3, mode, clip, last, total);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+extern "C" int dm_sampler_step_dev(float* z, const float* pred, const float* noise, const float* coefs,
+                                   long long* step, const int64_t* t_table, int64_t* t_out, int n_steps, int B, int mode,
+                                   int clip, long total, void* stream) {
+  DM_REQUIRE(z && pred && coefs && step && t_table && t_out && total > 0 && n_steps > 0 && B > 0 && mode >= 0 && mode <= 2,
+             DM_ERR_ARG, "dm_sampler_step_dev: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sampler_step_dev_kernel, dim3(grid_for(total)), dim3(NT), 0, st, z, pred, noise, coefs, step, n_steps,
+                     mode, clip, total);
+  DM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sampler_tick_kernel, dim3(1), dim3(NT), 0, st, step, t_table, t_out, n_steps, B);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -3,6 +3,8 @@
 Every per-step scalar (DDPM coefficient tables, DDIM alpha/sigma pairs, Euler dt) is computed ONCE per
 `sample()` call on the host with the reference's own arithmetic and dtypes, so the loop body is: one UNet
 forward (pred_fn) + one fused in-place update kernel, with no table upload and no device->host sync per step.
+A pred_fn that offers `run_loop` (harness.generate.GraphedPredictor) takes the whole loop over: forward, noise draw
+and update are then ONE captured HIP graph replayed n_steps times, the step's scalars coming from a device table.
 """
 from typing import Callable, Optional
 
@@ -51,6 +53,20 @@ class BaseSampler:
         raise NotImplementedError()
 
     # shared loop plumbing -------------------------------------------------------------------------------
+    def _loop(self, state, t_steps, t_rows, rows, mode, clip, pred_fn, gen=None):
+        """rows[i] = (c0, c1, c2, c3) of step i (see dm_sampler_step); gen: the noise generator of DDPM, else None."""
+        run_loop = getattr(pred_fn, "run_loop", None)
+        if run_loop is not None and not self.pbar:
+            return run_loop(state, t_steps, rows, mode, clip, gen)
+        n = self.n_steps
+        for i in self.prepare_iterator(range(n)):
+            pred = pred_fn(state, t_rows[i])
+            last = i == n - 1
+            noise = torch.randn_like(state, generator=gen) if (gen is not None and not last) else None
+            c0, c1, c2, c3 = rows[i]
+            ops.sampler_step(state, pred, noise, c0, c1, c2, c3, mode, clip, last)
+        return state
+
     def _begin(self, z, scheduler):
         t_steps = timestep_grid(scheduler.n_steps, self.n_steps)
         # one [n_steps, B] device tensor: row i is the t argument of step i (no per-step host->device traffic)
@@ -73,12 +89,8 @@ class DDPMSampler(BaseSampler):
         inv_sqrt_alpha = (1 / torch.sqrt(1 - beta)).tolist()
         sigma = torch.sqrt(beta).tolist()
 
-        for i in self.prepare_iterator(range(self.n_steps)):
-            t = int(t_steps[i])
-            eps_pred = pred_fn(state, t_rows[i])
-            noise = torch.randn_like(state, generator=gen) if i < self.n_steps - 1 else None
-            ops.sampler_step(state, eps_pred, noise, inv_sqrt_alpha[t], coef[t], sigma[t], 0.0, 0, False, False)
-        return state.to(z.dtype)
+        rows = [(inv_sqrt_alpha[t], coef[t], sigma[t], 0.0) for t in t_steps.tolist()]
+        return self._loop(state, t_steps, t_rows, rows, 0, False, pred_fn, gen).to(z.dtype)
 
 
 class DDIMSampler(BaseSampler):
@@ -94,12 +106,9 @@ class DDIMSampler(BaseSampler):
         alpha = torch.sqrt(sch.alpha_sq).to(state.dtype).tolist()
         sigma = torch.sqrt(sch.sigma_sq).to(state.dtype).tolist()
 
-        for i in self.prepare_iterator(range(self.n_steps)):
-            eps_pred = pred_fn(state, t_rows[i])
-            last = i == self.n_steps - 1
-            a_next, s_next = (0.0, 0.0) if last else (alpha[i + 1], sigma[i + 1])
-            ops.sampler_step(state, eps_pred, None, alpha[i], sigma[i], a_next, s_next, 1, self.clip_latent, last)
-        return state.to(z.dtype)
+        n = self.n_steps
+        rows = [(alpha[i], sigma[i]) + ((alpha[i + 1], sigma[i + 1]) if i < n - 1 else (0.0, 0.0)) for i in range(n)]
+        return self._loop(state, t_steps, t_rows, rows, 1, self.clip_latent, pred_fn).to(z.dtype)
 
 
 class RectifiedFlowEulerSampler(BaseSampler):
@@ -112,7 +121,5 @@ class RectifiedFlowEulerSampler(BaseSampler):
         nxt = torch.cat([sig[1:], torch.zeros(1, dtype=sig.dtype)])
         dt = (nxt - sig).tolist()        # fp32 subtraction as in the reference; negative: backward Euler steps
 
-        for i in self.prepare_iterator(range(self.n_steps)):
-            v_pred = pred_fn(state, t_rows[i])
-            ops.sampler_step(state, v_pred, None, dt[i], 0.0, 0.0, 0.0, 2, False, False)
-        return state.to(z.dtype)
+        rows = [(d, 0.0, 0.0, 0.0) for d in dt]
+        return self._loop(state, t_steps, t_rows, rows, 2, False, pred_fn).to(z.dtype)

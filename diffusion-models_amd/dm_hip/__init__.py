@@ -91,6 +91,7 @@ _SIGNATURES = {
     "dm_mse_loss_fwd": (c_int, [P, P, P, P, P, c_long, c_int, P]),
     "dm_mse_loss_bwd": (c_int, [P, P, P, P, P, c_long, c_int, P]),
     "dm_sampler_step": (c_int, [P, P, P, c_float, c_float, c_float, c_float, c_int, c_int, c_int, c_long, P]),
+    "dm_sampler_step_dev": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_long, P]),
     "dm_cfg_combine": (c_int, [P, P, P, c_float, c_long, P]),
     "dm_sumsq_partials": (c_int, []),
     "dm_grad_norm": (c_int, [P, c_long, P, P, P]),

@@ -827,6 +827,25 @@ def sampler_step(z, pred, noise, c0, c1, c2, c3, mode, clip, last):
     return z
 
 
+def sampler_step_dev(z, pred, noise, coefs, step, t_table, t_out, n_steps, mode, clip):
+    """The sampler update of loop step step[0] with its scalars from the device table coefs [n_steps, 4], followed by
+    step[0] += 1 and t_out[:] = t_table[step[0]] (see dm_sampler_step_dev): graph-capturable, no host scalars."""
+    _require_device(z, "sampler_step_dev")
+    if z.dtype != torch.float32 or not z.is_contiguous():
+        raise RuntimeError("sampler_step_dev: z must be a contiguous fp32 tensor")
+    if (coefs.dtype != torch.float32 or tuple(coefs.shape) != (n_steps, 4) or not coefs.is_contiguous()
+            or t_table.dtype != torch.int64 or t_table.numel() != n_steps or step.dtype != torch.int64
+            or t_out.dtype != torch.int64 or t_out.numel() != z.shape[0]):
+        raise RuntimeError("sampler_step_dev: coefs must be fp32 [n_steps, 4], t_table int64 [n_steps], step int64 [1], "
+                           "t_out int64 [batch]")
+    p32 = f32c(pred)
+    n32 = f32c(noise) if noise is not None else None
+    check(lib.dm_sampler_step_dev(z.data_ptr(), p32.data_ptr(), _p(n32), coefs.data_ptr(), step.data_ptr(),
+                                  t_table.data_ptr(), t_out.data_ptr(), n_steps, z.shape[0], mode, int(clip), z.numel(),
+                                  _stream()))
+    return z
+
+
 def cfg_combine(pred_uncond, pred_cond, scale):
     _require_device(pred_uncond, "cfg_combine")
     u, c = f32c(pred_uncond), f32c(pred_cond)

@@ -7,8 +7,8 @@ shards are gathered once at the end.
 
 The UNet forward of a sampler step is ~150 kernel launches whose arguments do not change from step to step
 except for the contents of z and t, so it is captured ONCE per (batch size, guidance mode) into a HIP graph
-that reads the sampler's own state buffer in place; a step is then one 8-byte-per-row copy of t, one graph
-launch and one fused update kernel.
+together with the sampler's update kernel (its per-step scalars come from a device table indexed by a device step
+counter, which also writes the next step's t) and, for DDPM, the noise draw: a sampler step is ONE graph launch.
 """
 from typing import Callable, Dict, Optional, Tuple
 
@@ -50,6 +50,8 @@ class GraphedPredictor:
         self.warmup = warmup
         self.graph = None
         self.z = self.t = self.out = None
+        self.loops = {}
+        self.replay_limit = None   # when set, run_loop stops after this many steps (capture / warm-up runs)
 
     def _capture(self, z, t):
         self.z = z
@@ -63,6 +65,53 @@ class GraphedPredictor:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = self.pred_fn(self.z, self.t)
+
+    # ---- a whole sampling loop as replays of ONE graph (offered to the samplers as pred_fn.run_loop) -----------
+    def _capture_loop(self, key, state, n_steps, mode, clip, noisy):
+        """Capture [UNet forward -> (noise draw) -> sampler update from the device table -> step counter / next t] once
+        per (shape, n_steps, sampler family); nothing in it depends on the step index."""
+        from dm_hip import ops
+        dev, B = state.device, state.shape[0]
+        L = {"z": torch.empty_like(state), "t": torch.zeros(B, dtype=torch.int64, device=dev),
+             "step": torch.zeros(1, dtype=torch.int64, device=dev),
+             "coefs": torch.zeros((n_steps, 4), dtype=torch.float32, device=dev),
+             "t_table": torch.zeros(n_steps, dtype=torch.int64, device=dev),
+             "gen": torch.Generator(device=dev) if noisy else None}
+        L["z"].copy_(state)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(self.warmup):  # packs weights, primes the allocator
+                self.pred_fn(L["z"], L["t"])
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        if noisy:
+            graph.register_generator_state(L["gen"])
+        with torch.cuda.graph(graph), torch.no_grad():
+            pred = self.pred_fn(L["z"], L["t"])
+            noise = torch.randn_like(L["z"], generator=L["gen"]) if noisy else None
+            ops.sampler_step_dev(L["z"], pred, noise, L["coefs"], L["step"], L["t_table"], L["t"], n_steps, mode, clip)
+        L["graph"] = graph
+        self.loops[key] = L
+        return L
+
+    def run_loop(self, state, t_steps, rows, mode, clip, gen=None):
+        """The sampler loop `for i: pred = pred_fn(state, t_i); update(state, pred, rows[i])` (diffusion/sampler.py) as
+        n_steps replays of one HIP graph. gen: DDPM's noise generator (its seed and offset are taken over, so the noise
+        is the sequence eager randn_like calls would draw). Returns the final state (a new tensor)."""
+        n_steps = len(rows)
+        key = (tuple(state.shape), n_steps, mode, bool(clip), gen is not None)
+        L = self.loops.get(key) or self._capture_loop(key, state, n_steps, mode, clip, gen is not None)
+        L["z"].copy_(state)
+        L["coefs"].copy_(torch.tensor(rows, dtype=torch.float32))
+        L["t_table"].copy_(t_steps.to(torch.int64))
+        L["t"].copy_(L["t_table"][:1].expand(state.shape[0]))
+        L["step"].zero_()
+        if gen is not None:
+            L["gen"].set_state(gen.get_state())
+        for _ in range(n_steps if self.replay_limit is None else min(n_steps, self.replay_limit)):
+            L["graph"].replay()
+        return L["z"].clone()
 
     def __call__(self, z, t):
         if self.graph is None or z.shape != self.z.shape or z.dtype != self.z.dtype:

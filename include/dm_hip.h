@@ -281,6 +281,14 @@ int dm_mse_loss_bwd(const float* pred, const float* x, const float* eps, const f
  */
 int dm_sampler_step(float* z, const float* pred, const float* noise, float c0, float c1, float c2, float c3, int mode,
                     int clip, int last, long total, void* stream);
+/* The same update for loop step i = step[0] (device counter), its scalars (c0..c3) read from row i of the device table
+ * `coefs` [n_steps][4]; last = (i == n_steps-1), on which `noise` is ignored. Afterwards step[0] += 1 and
+ * t_out[0..B) = t_table[step[0]] (clamped to the last entry): the timestep argument of the next UNet forward. Nothing in
+ * the launch depends on the step index, so ONE captured HIP graph (UNet forward + this call) replays a whole sampling
+ * loop (diffusion/sampler.py:76-84, 111-130, 152-162) without per-step host work. Replays beyond n_steps change nothing. */
+int dm_sampler_step_dev(float* z, const float* pred, const float* noise, const float* coefs, long long* step,
+                        const int64_t* t_table, int64_t* t_out, int n_steps, int B, int mode, int clip, long total,
+                        void* stream);
 /* out = u + s * (c - u)   (modeling/predictor.py:29) */
 int dm_cfg_combine(const float* pred_uncond, const float* pred_cond, float* out, float s, long total, void* stream);
 
