@@ -93,6 +93,9 @@ _SIGNATURES = {
     "dm_sampler_step": (c_int, [P, P, P, c_float, c_float, c_float, c_float, c_int, c_int, c_int, c_long, P]),
     "dm_sampler_step_dev": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_long, P]),
     "dm_cfg_combine": (c_int, [P, P, P, c_float, c_long, P]),
+    "dm_u8_batch": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_long, c_int, P]),
+    "dm_nn2_ws_floats": (c_long, [c_int, c_int]),
+    "dm_nn2_distances": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P]),
     "dm_sumsq_partials": (c_int, []),
     "dm_grad_norm": (c_int, [P, c_long, P, P, P]),
     "dm_adamw_ema_step": (c_int, [P, P, P, P, P, P, P, c_float, c_long] + [c_float] * 8 + [P, P]),

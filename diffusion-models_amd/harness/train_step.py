@@ -43,18 +43,27 @@ class FlatArena:
         self.data = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.names = [n for n, _ in self.params]
-        for (n, p), o in zip(self.params, self.offsets):
-            if id(p) in conv_weights and p.dim() == 4:
-                # physical [Cout][KH][KW][Cin]: the layout the weight-gradient kernel produces
-                co, ci, kh, kw = p.shape
-                view = self.data[o:o + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
-                gview = self.grad[o:o + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
-            else:
-                view = self.data[o:o + p.numel()].view(p.shape)
-                gview = self.grad[o:o + p.numel()].view(p.shape)
+        self.shapes = [tuple(p.shape) for _, p in self.params]
+        # conv weights are stored physically [Cout][KH][KW][Cin]: the layout the weight-gradient kernel produces
+        self.ohwi = [id(p) in conv_weights and p.dim() == 4 for _, p in self.params]
+        for i, (n, p) in enumerate(self.params):
+            view = self.view_of(self.data, i)
             view.copy_(p.data)
             p.data = view
-            p.grad = gview
+            p.grad = self.view_of(self.grad, i)
+
+    def view_of(self, buf: torch.Tensor, i: int) -> torch.Tensor:
+        """Parameter i's slice of an arena-shaped buffer (data, grad, Adam moments, EMA shadow) as a view of the
+        parameter's logical shape (for a conv weight: the reference's [Cout, Cin, KH, KW], strided)."""
+        o, shape = self.offsets[i], self.shapes[i]
+        n = 1
+        for d in shape:
+            n *= d
+        flat = buf[o:o + n]
+        if self.ohwi[i]:
+            co, ci, kh, kw = shape
+            return flat.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return flat.view(shape)
 
 
 class TrainStep:
@@ -251,14 +260,76 @@ class TrainStep:
         self._backward_and_update(loss)
         return loss.detach(), self.norm.clone()
 
-    # ---- EMA weights in / out (train.py:363-373 saves model.pt and ema_model.pt) ---------------------------
+    # ---- weights, optimizer and EMA state in / out ------------------------------------------------------------
+    def model_state_dict(self):
+        """The model's state dict in the reference's layout (contiguous tensors): what train.py:366 saves as model.pt."""
+        return {k: v.detach().contiguous().clone() for k, v in self.model.state_dict().items()}
+
     def ema_state_dict(self):
-        sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
-        for (n, p), o in zip(self.arena.params, self.arena.offsets):
-            flat = self.ema[o:o + p.numel()]
-            if p.dim() == 4 and not p.is_contiguous():
-                co, ci, kh, kw = p.shape
-                sd[n] = flat.view(co, kh, kw, ci).permute(0, 3, 1, 2).contiguous()
-            else:
-                sd[n] = flat.view(p.shape).clone()
+        """The EMA weights as a model state dict: what train.py:367-371 saves as ema_model.pt."""
+        if self.ema is None:
+            raise RuntimeError("ema_state_dict: this TrainStep was built with use_ema=False")
+        sd = self.model_state_dict()
+        for i, n in enumerate(self.arena.names):
+            sd[n] = self.arena.view_of(self.ema, i).contiguous().clone()
         return sd
+
+    def state_dict(self):
+        """Everything train.py:375-392 (save_latest_ckpt) keeps to resume a run, in the formats of the objects the
+        reference holds: torch.optim.AdamW.state_dict() (per-parameter step / exp_avg / exp_avg_sq in parameter
+        order) and diffusers' EMAModel.state_dict() (shadow_params list + optimization_step + warm-up settings)."""
+        a = self.arena
+        n = len(a.params)
+        opt_state = {}
+        if self.steps > 0:
+            for i in range(n):
+                opt_state[i] = {"step": torch.tensor(float(self.steps)),
+                                "exp_avg": a.view_of(self.m, i).contiguous().clone(),
+                                "exp_avg_sq": a.view_of(self.v, i).contiguous().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(n))}
+        sd = {"global_steps": self.steps, "model_state_dict": self.model_state_dict(),
+              "optimizer_state_dict": {"state": opt_state, "param_groups": [group]}}
+        if self.ema is not None:
+            ig, pw, mx = self.ema_cfg
+            sd["ema_model_state_dict"] = {
+                "decay": mx, "min_decay": 0.0, "optimization_step": self.steps, "update_after_step": 0,
+                "use_ema_warmup": True, "inv_gamma": ig, "power": pw,
+                "shadow_params": [a.view_of(self.ema, i).contiguous().clone() for i in range(n)]}
+        return sd
+
+    def load_state_dict(self, sd):
+        """Inverse of state_dict() (train.py:394-415 load_latest_ckpt): a run resumed from it continues exactly as the
+        uninterrupted run would (same Adam bias corrections, same EMA warm-up position)."""
+        a = self.arena
+        n = len(a.params)
+        self.model.load_state_dict(sd["model_state_dict"])
+        opt = sd["optimizer_state_dict"]["state"]
+        self.m.zero_()
+        self.v.zero_()
+        steps = int(sd.get("global_steps", 0))
+        for i in range(n):
+            st = opt.get(i, opt.get(str(i)))
+            if st is None:
+                continue
+            a.view_of(self.m, i).copy_(st["exp_avg"])
+            a.view_of(self.v, i).copy_(st["exp_avg_sq"])
+            steps = max(steps, int(float(st["step"])))
+        g = sd["optimizer_state_dict"]["param_groups"][0]
+        self.lr, self.betas, self.eps, self.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        if self.ema is not None:
+            e = sd.get("ema_model_state_dict")
+            if e is None:
+                self.ema.copy_(a.data)
+            else:
+                for i, t in enumerate(e["shadow_params"]):
+                    a.view_of(self.ema, i).copy_(t)
+                self.ema_cfg = (e.get("inv_gamma", self.ema_cfg[0]), e.get("power", self.ema_cfg[1]),
+                                e.get("decay", self.ema_cfg[2]))
+                steps = max(steps, int(e.get("optimization_step", 0)))
+        self.steps = steps
+        self.step_dev.fill_(steps)
+        a.grad.zero_()
+        self.refresh_packed()
+        ops.WEIGHTS_EPOCH += 1

@@ -310,6 +310,26 @@ int dm_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, 
 int dm_optimizer_tick(long long* step, float* hyper, float lr, float b1, float b2, float ema_inv_gamma, float ema_power,
                       float ema_max_decay, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Either side of the path: the data set resident in HBM, and the memorisation metric of the evaluation.
+ */
+/* A training batch from a uint8 image set in device memory, data [n_items][H][W][C] (the layout of torchvision's
+ * CIFAR10.data; MNIST is C = 1): out[b][c][h][w] (fp32, NCHW) = normalise(data[idx[b]][h'][w'][c]), h'/w' mirrored
+ * when flip[b] has bit 1 / bit 0 set (flip and idx nullable: no flips / rows 0..B-1).
+ *   mode 0: ((v / 255) - 0.5) / 0.5  - ToTensor + Normalize(0.5, 0.5), the DataLoader transform (train.py:111-114)
+ *   mode 1: v / 127.5 - 1            - the data_tensor form (train.py:124-125, 136)
+ * each a separately rounded fp32 operation, bit-identical to torch. Replaces DataLoader + transforms
+ * (train.py:312-329, utils/augmentation.py:6-18) for data sets that fit HBM. */
+int dm_u8_batch(const uint8_t* data, const int64_t* idx, const uint8_t* flip, float* out, int B, int C, int H, int W,
+                long n_items, int mode, void* stream);
+/* d1[i], d2[i] = the two smallest L2 distances from generated row i (fp32 [n_gen][D]) to the reference rows (fp32
+ * [n_ref][D], n_ref >= 2): torch.cdist(gen, ref).topk(2, largest=False) of utils/validate_memo.py:13-18, as an fp32
+ * MFMA GEMM with the selection fused in (no [n_gen][n_ref] matrix is materialised).
+ * ws: scratch of dm_nn2_ws_floats(n_gen, n_ref) floats. */
+long dm_nn2_ws_floats(int n_gen, int n_ref);
+int dm_nn2_distances(const float* gen, const float* ref, float* d1, float* d2, int n_gen, int n_ref, int D, float* ws,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,7 @@ def pytest_configure(config):
 # reference fixtures, and only then the harness's self-consistency and multi-process tests - under `pytest -x` a
 # failure in a late file cannot hide the parity tests. Unlisted files run after the listed ones, by name.
 _FILE_ORDER = ["test_oracle_golden.py", "test_host_logic.py", "test_gpu_ops.py", "test_gpu_model.py",
-               "test_generate.py", "test_gpu_harness.py", "test_ddp_gloo.py", "test_ddp_gpu.py"]
+               "test_generate.py", "test_gpu_harness.py", "test_gpu_io.py", "test_ddp_gloo.py", "test_ddp_gpu.py"]
 
 
 def pytest_collection_modifyitems(config, items):

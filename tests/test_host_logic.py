@@ -119,3 +119,48 @@ def test_operators_refuse_cpu_tensors():
     m = get_model("unet", **TINY_CFG)
     with pytest.raises(RuntimeError, match="GPU only"):
         m(torch.zeros(1, 3, 16, 16), torch.zeros(1, dtype=torch.int64))
+
+
+def test_epoch_permutation_is_the_dataloaders_order():
+    """harness.data.epoch_permutation restates what DataLoader(shuffle=True, generator=g) draws per epoch (train.py:
+    316-327): checked against torch's own DataLoader over two epochs."""
+    import torch
+    from torch.utils.data import DataLoader, TensorDataset
+    from harness.data import epoch_permutation
+    n = 103
+    ds = TensorDataset(torch.arange(n))
+    rng = torch.Generator().manual_seed(42)
+    loader = DataLoader(ds, batch_size=16, shuffle=True, drop_last=False, num_workers=0, generator=rng)
+    mine = torch.Generator().manual_seed(42)
+    for _ in range(2):
+        order = torch.cat([b[0] for b in loader])
+        assert torch.equal(order, epoch_permutation(n, mine))
+
+
+def test_fid_extrapolation_and_frechet_distance():
+    """utils/fid_infinity.py: the regression of subset FIDs on 1/n; Frechet distance known answers."""
+    import numpy as np
+    import torch
+    from scipy.stats import linregress
+    from harness.evaluation import calculate_frechet_distance, fid_extrapolation
+    mu, sig = np.array([1.0, -2.0, 0.5]), np.diag([1.0, 4.0, 9.0])
+    assert abs(calculate_frechet_distance(mu, sig, mu, sig)) < 1e-9
+    # diagonal Gaussians: ||dmu||^2 + sum (sqrt(a) - sqrt(b))^2
+    sig2 = np.diag([4.0, 1.0, 9.0])
+    assert abs(calculate_frechet_distance(mu, sig, mu + 1, sig2) - (3.0 + 1.0 + 1.0 + 0.0)) < 1e-9
+    g = torch.Generator().manual_seed(0)
+    feats = torch.randn(2000, 8, generator=g) * 1.5 + 0.3
+    ref_mu, ref_sigma = np.zeros(8), np.eye(8)
+    sizes = [500, 1000, 2000]
+    r = fid_extrapolation(feats, ref_mu, ref_sigma, sizes, target_n=50_000, seed=42)
+    # the same subsets by hand
+    rng = np.random.default_rng(42)
+    f = feats.numpy()
+    fids = []
+    for n in sizes:
+        sub = f[rng.choice(2000, size=n, replace=False)]
+        fids.append(calculate_frechet_distance(sub.mean(0), np.cov(sub, rowvar=False), ref_mu, ref_sigma))
+    fit = linregress([1 / n for n in sizes], fids)
+    assert np.allclose(r["fids"], fids) and abs(r["fid_infinity"] - fit.intercept) < 1e-12
+    assert abs(r["fid_target"] - (fit.slope / 50_000 + fit.intercept)) < 1e-12
+    assert r["subset_sizes"] == sizes and 0 <= r["regression"]["r_squared"] <= 1
