@@ -32,9 +32,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
 def measured_conv_traffic():
-    """Average HBM-side bytes per forward/data-gradient conv launch, from profiles/r01_conv_traffic.json (rocprofv3
+    """Average HBM-side bytes per forward/data-gradient conv launch, from profiles/r02_conv_traffic.json (rocprofv3
     --pmc passes of this benchmark; counters cannot be read from inside the run). None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -437,7 +437,7 @@ def main():
                     "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "bytes/launch",
-                    "traffic_source": "profiles/r01_conv_traffic.json (rocprofv3 --pmc passes of this benchmark: "
+                    "traffic_source": "profiles/r02_conv_traffic.json (rocprofv3 --pmc passes of this benchmark: "
                                       "2 x FETCH_SIZE + WRITE_SIZE; not measured by this run)" if traffic else None,
                     "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["launches"]),
                     "launches_per_step": ig["launches"], "ms_per_step": round(ig["ms"], 3),

@@ -20,6 +20,7 @@
 #include <mutex>
 
 extern int g_dm_gn_fused;
+extern int g_dm_gn_bwd16;
 
 // Scratch of the entry point that allocates nothing (dm_groupnorm_act_fwd_noalloc): a fixed device array that
 // stands in for the caller-provided workspace. Every GPU the library runs on holds its own copy at its own
@@ -555,7 +556,8 @@ __device__ __forceinline__ f32x2_t silu_grad_pair(f32x2_t u) {
   return sg * (u * (1.0f - sg) + 1.0f);
 }
 
-template <int PPT, int MAXT, bool ACT, bool EXTRA>
+// EXACT: the slab tiles the workgroup exactly (HW = PPT * pixel lanes, all 8 vector lanes inside C): no masking
+template <int PPT, int MAXT, bool ACT, bool EXTRA, bool EXACT>
 __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
   __shared__ float red[(MAXT / 64) * 3 * 64];
   __shared__ float sums[3 * 64];
@@ -567,14 +569,24 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
   const int c = c0 + 8 * v;
   const bool cok = 8 * v < a.sw && c < a.C;
   const size_t base = (size_t)b * a.HW;
-  u32x4_t xr[PPT], dr[PPT];
+  // the slab as individual 32-bit registers (a 4-register vector that is updated element by element has to be
+  // re-assembled in fresh registers wherever it is used whole, which doubles the footprint at that point)
+  unsigned xr[PPT][4], dr[PPT][4];
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     const int p = pl + i * PLN;
-    const bool ok = cok && p < a.HW;
-    xr[i] = load_slab_x(a, base, p, c, cok);
-    const u32x4_t d = *(const u32x4_t*)(a.dy + (base + (ok ? p : 0)) * a.C + (cok ? c : 0));
-    dr[i] = ok ? d : u32x4_t{0, 0, 0, 0};
+    u32x4_t xv, dv;
+    if (EXACT) {
+      xv = __builtin_bit_cast(u32x4_t, load_x(a, base + p, c));
+      dv = *(const u32x4_t*)(a.dy + (base + p) * a.C + c);
+    } else {
+      const bool ok = cok && p < a.HW;
+      xv = load_slab_x(a, base, p, c, cok);
+      dv = *(const u32x4_t*)(a.dy + (base + (ok ? p : 0)) * a.C + (cok ? c : 0));
+      if (!ok) dv = u32x4_t{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { xr[i][k] = xv[k]; dr[i][k] = dv[k]; }
   }
   for (int cc = threadIdx.x; cc < 64; cc += blockDim.x) {
     const int cj = c0 + cc;
@@ -600,7 +612,7 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
     f32x2_t p0[2] = {{0.f, 0.f}, {0.f, 0.f}}, p1[2] = {{0.f, 0.f}, {0.f, 0.f}}, p2[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const float live = pl + i * PLN < a.HW ? 1.f : 0.f;   // xhat of a lane beyond the image must not be summed
+      const float live = (EXACT || pl + i * PLN < a.HW) ? 1.f : 0.f;   // xhat of a lane beyond the image must not be summed
       // an opaque copy of the pixel's words: the unpacking then cannot be hoisted above this point, so the compiler
       // works through the slab one pixel at a time instead of widening all of it to floats first
       unsigned xw[2] = {xr[i][2 * h], xr[i][2 * h + 1]}, dw[2] = {dr[i][2 * h], dr[i][2 * h + 1]};
@@ -617,7 +629,7 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
         }
         p0[q] += du;
         p1[q] += du * xh;
-        p2[q] += xh * live;
+        p2[q] += EXACT ? xh : xh * live;
         if (ACT) dr[i][2 * h + q] = pack_pair(du);   // dy is consumed: its register takes du for the second pass
       }
     }
@@ -628,7 +640,9 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
   slab_sum_finish<3>(red, sums);
   // make the slab opaque here: otherwise the compiler keeps per-element values of the first pass alive for the second
 #pragma unroll
-  for (int i = 0; i < PPT; ++i) asm volatile("" : "+v"(xr[i]), "+v"(dr[i]));
+  for (int i = 0; i < PPT; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(xr[i][k]), "+v"(dr[i][k]));
   const float inv_n = 1.0f / (float)(a.cg * a.HW);
   const int ng = a.sw / a.cg;
   for (int gl = threadIdx.x; gl < ng; gl += blockDim.x) {
@@ -685,11 +699,11 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     int p = pl + i * PLN;
-    u32x4_t xw = xr[i], dw = dr[i];
+    unsigned xw[4] = {xr[i][0], xr[i][1], xr[i][2], xr[i][3]}, dw[4] = {dr[i][0], dr[i][1], dr[i][2], dr[i][3]};
     // opaque: unpacking and address arithmetic stay with their pixel instead of being hoisted for the whole slab
-    asm volatile("" : "+v"(xw), "+v"(dw), "+v"(p));
+    asm volatile("" : "+v"(xw[0]), "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]), "+v"(dw[0]), "+v"(dw[1]), "+v"(dw[2]), "+v"(dw[3]), "+v"(p));
     u32x4_t ew = {0, 0, 0, 0};
-    if (EXTRA) ew = *(const u32x4_t*)(a.dextra + (base + min(p, a.HW - 1)) * a.C + c);
+    if (EXTRA) ew = *(const u32x4_t*)(a.dextra + (base + (EXACT ? p : min(p, a.HW - 1))) * a.C + c);
     u32x4_t ow;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -702,7 +716,7 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
       if (EXTRA) r += bf16_pair(ew[w]);
       ow[w] = pack_pair(r);
     }
-    if (p < a.HW) *(u32x4_t*)(dxb + (size_t)p * dxs) = ow;
+    if (EXACT || p < a.HW) *(u32x4_t*)(dxb + (size_t)p * dxs) = ow;
   }
 }
 
@@ -717,27 +731,30 @@ int slab_width(int cg) {
   return l <= 64 ? 64 / l * l : 0;
 }
 // pixels per thread: the smallest of 1, 2, 4, 8 with at most 64 pixel lanes (128 beyond 512 pixels)
-int fused_ppt(const GnArgs& a) {
+int fused_ppt(const GnArgs& a, bool bwd) {
   for (int ppt = 1; ppt < 8; ppt *= 2)
     if (dm_cdiv(a.HW, ppt) <= 64) return ppt;
-  return 8;
+  return (bwd && g_dm_gn_bwd16 && a.HW > 512) ? 16 : 8;
 }
-int fused_threads(const GnArgs& a) {   // one thread per (pixel lane, 8-channel vector)
-  const int lanes = dm_cdiv(a.HW, fused_ppt(a));
+int fused_threads(const GnArgs& a, bool bwd) {   // one thread per (pixel lane, 8-channel vector)
+  const int lanes = dm_cdiv(a.HW, fused_ppt(a, bwd));
   return dm_cdiv(lanes * 8, 64) * 64;
 }
 
 template <bool BWD>
 void launch_fused(const GnArgs& a, hipStream_t st) {
-  const dim3 grid(dm_cdiv(a.C, a.sw), a.B), block(fused_threads(a));
-  const int ppt = fused_ppt(a);
+  const dim3 grid(dm_cdiv(a.C, a.sw), a.B), block(fused_threads(a, BWD));
+  const int ppt = fused_ppt(a, BWD);
+  const bool exact = a.sw == 64 && a.C % 64 == 0 && a.HW == ppt * (int)(block.x >> 3);
 #define DM_GN_LAUNCH(P, T)                                                                                   \
   do {                                                                                                       \
     if (BWD) {                                                                                               \
-      if (a.act && a.dextra) hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, true, true>), grid, block, 0, st, a);   \
-      else if (a.act) hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, true, false>), grid, block, 0, st, a);   \
-      else if (a.dextra) hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, false, true>), grid, block, 0, st, a); \
-      else hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, false, false>), grid, block, 0, st, a);             \
+      if (exact && a.act && a.dextra) hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, true, true, true>), grid, block, 0, st, a); \
+      else if (exact && a.act) hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, true, false, true>), grid, block, 0, st, a); \
+      else if (a.act && a.dextra) hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, true, true, false>), grid, block, 0, st, a);   \
+      else if (a.act) hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, true, false, false>), grid, block, 0, st, a);   \
+      else if (a.dextra) hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, false, true, false>), grid, block, 0, st, a); \
+      else hipLaunchKernelGGL((gn_bwd_fused_kernel<P, T, false, false, false>), grid, block, 0, st, a);             \
     } else if (a.act) hipLaunchKernelGGL((gn_fwd_fused_kernel<P, T, true>), grid, block, 0, st, a);          \
     else hipLaunchKernelGGL((gn_fwd_fused_kernel<P, T, false>), grid, block, 0, st, a);                      \
   } while (0)
@@ -745,6 +762,7 @@ void launch_fused(const GnArgs& a, hipStream_t st) {
   else if (ppt == 2) DM_GN_LAUNCH(2, 512);
   else if (ppt == 4) DM_GN_LAUNCH(4, 512);
   else if (a.HW <= 512) DM_GN_LAUNCH(8, 512);
+  else if (BWD && g_dm_gn_bwd16) DM_GN_LAUNCH(16, 512);
   else DM_GN_LAUNCH(8, 1024);
 #undef DM_GN_LAUNCH
 }
