@@ -282,8 +282,24 @@ def _groupnorm_case(B, C1, C2, H, W, act, ss, pre):
         assert rel_err(pred_.grad, prer.grad) < 2e-4
 
 
-@pytest.mark.parametrize("B,L,H,D", [(2, 64, 8, 8), (2, 49, 16, 8), (1, 256, 4, 16), (3, 16, 2, 32), (1, 100, 1, 64)])
-def test_attention_fwd_bwd(B, L, H, D):
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("B,L,H,D", [(2, 64, 8, 8), (2, 49, 16, 8), (1, 256, 4, 16), (3, 16, 2, 32), (1, 100, 1, 64),
+                                     (3, 70, 5, 16), (2, 1, 3, 8), (128, 64, 64, 8)])
+def test_attention_fwd_bwd(B, L, H, D, mfma):
+    """Head dims 8 and 16 run on the matrix cores (mfma=1) or, switched off, on the VALU kernels that also serve
+    head dims 32 and 64; both against torch's fp32 scaled_dot_product_attention. The last case is the cos_cifar
+    mid-block attention at training batch size."""
+    from dm_hip import lib
+    if not mfma and D > 16:
+        pytest.skip("head dims above 16 have one implementation")
+    lib.dm_config_set(b"attn_mfma", mfma)
+    try:
+        _attention_case(B, L, H, D)
+    finally:
+        lib.dm_config_set(b"attn_mfma", 1)
+
+
+def _attention_case(B, L, H, D):
     from dm_hip import ops
     rs = np.random.RandomState(B + L + H + D)
     qkv = q(rnd(rs, B, L, 3 * H * D))
