@@ -282,7 +282,7 @@ def bench_sampling(args, cfg, device, rank, world):
                        n_steps=args.sample_steps, batch=args.sample_batch, repeats=args.steps, warmup=args.warmup,
                        use_graph=not args.no_graph)
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": f"sample imgs/sec @{row['n_steps']} steps ({row['sampler']})", "value": row["img_s"],
             "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(row["s_per_batch"] * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -294,9 +294,23 @@ def bench_sampling(args, cfg, device, rank, world):
             "roofline": {"bound": "mfma", "kernel": "UNet forward (all kernels of one sampler step)",
                          "achieved": row["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": row["frac"],
                          "traffic": None},
-            "cpu_baseline": None}), flush=True)
+            "cpu_baseline": None})
     if world > 1:
         dist.destroy_process_group()
+
+
+_REAL_STDOUT = None
+
+
+def emit(line: dict):
+    """The one JSON line, on the process's original stdout."""
+    text = json.dumps(line) + "\n"
+    if _REAL_STDOUT is None:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, text.encode())
 
 
 def main():
@@ -310,6 +324,10 @@ def main():
     ap.add_argument("--split-graph", action="store_true",
                     help="capture forward+backward and the optimizer tail as two graphs with the gradient all-reduce "
                          "between them (what runs on more than one GPU; on one GPU for testing)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="one GPU: create an RCCL process group of one rank and run the data-parallel collectives "
+                         "(implies --split-graph)")
+    ap.add_argument("--pg-port", type=int, default=29731)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--mode", choices=["train", "sample"], default="train",
@@ -327,11 +345,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.force_collectives:
+        args.split_graph = True
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world > 1 or args.force_collectives:
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the one JSON
+        # line by pointing file descriptor 1 at stderr for the run; emit() writes to the saved descriptor
+        sys.stdout.flush()
+        global _REAL_STDOUT
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
+    elif args.force_collectives:
+        # a process group of one rank over RCCL: every collective of the multi-GPU path really runs (one-GPU rehearsal)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{args.pg_port}", rank=0, world_size=1,
+                                device_id=device)
 
     cfg = load_cfg(args.config)
     if args.mode == "sample":
@@ -350,39 +382,46 @@ def main():
         run()
     torch.cuda.synchronize()
     split = world > 1 or args.split_graph
+    n_segments = None
     if not args.no_graph:
         try:
             ops.FORCE_REPACK = True
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                if not split:
+            if not split:
+                with torch.cuda.stream(side):
                     graph = torch.cuda.CUDAGraph()
                     run()  # warm-up on the capture stream
                     torch.cuda.synchronize()
                     with torch.cuda.graph(graph, stream=side):
                         loss_static = step.step(x, cls)
                     run = graph.replay
-                else:
-                    # More than one GPU: the two local phases are graphs, the bucketed all-reduce of the gradient
-                    # arena runs between them (collectives stay outside graph capture).
-                    graph, g_upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            else:
+                # More than one GPU: forward + backward is a chain of graphs cut wherever a gradient bucket becomes
+                # complete; at replay each bucket's RCCL all-reduce is issued behind the graph that completes it and
+                # runs beside the rest of backward (collectives stay outside graph capture); the optimizer tail is
+                # one more graph behind the last collective. --split-graph: the same form on one GPU (the cuts are
+                # made, the collectives run only with --force-collectives).
+                step.reducer.force = world == 1
+                with torch.cuda.stream(side):
                     step.forward_backward(x, cls); step.reduce(); step.update()  # warm-up on the capture stream
-                    torch.cuda.synchronize()
-                    with torch.cuda.graph(graph, stream=side):
-                        loss_static = step.forward_backward(x, cls)
-                    step.reduce()
-                    with torch.cuda.graph(g_upd, stream=side):
-                        step.update()
+                torch.cuda.current_stream().wait_stream(side)
+                loss_static = step.capture_segmented(x, cls, stream=side)
+                torch.cuda.current_stream().wait_stream(side)
+                g_upd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_upd, stream=side):
+                    step.update()
+                graph = step.segments[0][0]
+                n_segments = len(step.segments[0])
 
-                    def run():
-                        graph.replay()
-                        step.reduce()
-                        g_upd.replay()
+                def run():
+                    step.replay_segmented()
+                    g_upd.replay()
             torch.cuda.current_stream().wait_stream(side)
         except Exception as e:  # capture is an optimisation; the eager path is the same kernels
             sys.stderr.write(f"[bench] graph capture failed, running eagerly: {e!r}\n")
             graph = None
+            step.reducer.force = False
             run = lambda: step.step(x, cls)  # noqa: E731
         finally:
             ops.FORCE_REPACK = False
@@ -467,7 +506,8 @@ def main():
             "config": {"workload": f"arg_json/{args.config}.json train step (UNet {cfg['model_cfg']['block_out_channels']}, "
                                    f"{cfg['scheduler_cfg'].get('schedule', cfg['scheduler_type'])} schedule, AdamW+clip+EMA)",
                        "per_gpu_batch": batch, "global_batch": batch * world, "image": "3x32x32",
-                       "parallelism": f"dp{world}", "hip_graph": graph is not None},
+                       "parallelism": f"dp{world}", "hip_graph": graph is not None,
+                       **({"graph_segments": n_segments} if n_segments else {})},
             "step_tflops_achieved": round(step_tflop / (ms_per_step * 1e-3), 2) if step_tflop else None,
             "step_mfma_frac": round(step_tflop / (ms_per_step * 1e-3) / MFMA_BF16_PEAK_TFLOPS / world, 4) if step_tflop else None,
             "roofline": roof,
@@ -478,8 +518,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, budget_s=args.cpu_budget)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        emit(line)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

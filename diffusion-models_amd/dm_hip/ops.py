@@ -32,6 +32,16 @@ GRAD_READY = None
 SIDE_WGRAD = 0   # number of side streams to rotate over (0: off)
 _SIDE = {}
 _SIDE_NEXT = 0
+# Side streams that have been given work since whoever joins them last cleared this set. Under HIP-graph capture only
+# these may be waited for: a stream that took no part in the capture holds no captured work, and waiting for it from
+# the capturing stream is an error.
+SIDE_TOUCHED = set()
+# Tensors that kernels on a side stream read and that autograd may otherwise rewrite IN PLACE behind them: a gradient
+# handed back unchanged as the gradient of another input (the residual branch of a convolution) becomes the
+# accumulation buffer when a second gradient arrives for the same tensor, and autograd adds into it on the main
+# stream if it holds the last reference. A reference kept here until the side streams are joined forces that sum out
+# of place. (record_stream only guards the memory against reuse after the tensor dies.)
+SIDE_KEEP = []
 
 
 class SumCollector:
@@ -170,6 +180,7 @@ def _param_stream(tensors, enable=True):
     side = side_stream(tensors[0].device, _SIDE_NEXT % SIDE_WGRAD)
     _SIDE_NEXT += 1
     side.wait_stream(torch.cuda.current_stream())
+    SIDE_TOUCHED.add(side)
     for t in tensors:
         if t is not None:
             t.record_stream(side)
@@ -261,6 +272,7 @@ class _ConvFn(Function):
         dy = as_nhwc(dy)
         st = _stream()
         dx1 = dx2 = dw = db = None
+        done = []
         wparam, bparam = ctx.params
         wsink = _grad_sink(wparam, ohwi=True) if ctx.needs_input_grad[2] else None
         want_db = has_bias and ctx.needs_input_grad[3]
@@ -291,7 +303,7 @@ class _ConvFn(Function):
             check(lib.dm_conv2d_wgrad(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(),
                                       ws.data_ptr(), ws.numel() * 4, st_w))
             if wsink is not None:
-                _grad_done(wparam)
+                done.append(wparam)
             else:
                 dw = dwf.permute(0, 3, 1, 2)
                 if weight.dim() == 2:
@@ -306,7 +318,7 @@ class _ConvFn(Function):
                 # the twin's convolution produced the other term of the same sum (and ran with bias_grad=False)
                 check(lib.dm_colsum_bf16_dual(dy.data_ptr(), dbf.data_ptr(), tsink.data_ptr(), M, Cout, cws.data_ptr(),
                                               _deferred(True, cws), st_w))
-                _grad_done(twin)
+                done.append(twin)
             else:
                 check(lib.dm_colsum_bf16(dy.data_ptr(), dbf.data_ptr(), M, Cout, cws.data_ptr(),
                                          _deferred(bsink is not None and twin is None, cws), st_w))
@@ -317,10 +329,16 @@ class _ConvFn(Function):
                     else:
                         twin.grad.add_(g)   # in place: a gradient that is a view of a flat arena stays one
             if bsink is not None:
-                _grad_done(bparam)
+                done.append(bparam)
             else:
                 db = dbf
+        # reported only now, after this operator's last launch: a listener may close a HIP-graph capture at such a
+        # report, and the side stream forked above belongs to the capture that was open then
+        for prm in done:
+            _grad_done(prm)
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
+        if dres is not None and stream_w is not None:
+            SIDE_KEEP.append(dy)
         return dx1, dx2, dw, db, dres, None, None, None, None, None, None
 
 

@@ -30,7 +30,15 @@ class BucketedAllReduce:
     def __init__(self, grad_arena: torch.Tensor, offsets: Sequence[int], bucket_bytes: int = 25 << 20, group=None):
         self.grad = grad_arena
         self.group = group
-        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.have_group = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.have_group else 1
+        # Buckets are tracked (and on_bucket / collectives issued) on more than one rank; `force` turns the tracking on
+        # for a single rank too: with a process group of one rank the collectives then really run (a way to exercise
+        # the RCCL path on a one-GPU box), without a process group only on_bucket is called.
+        self.force = False
+        # Optional callable(bucket index): called INSTEAD of launching the bucket's all-reduce when the bucket becomes
+        # complete during backward (used to cut a HIP-graph capture there; the collective is issued at replay).
+        self.on_bucket = None
         self.buckets = cut_buckets(offsets, grad_arena.numel(), max(1, bucket_bytes // grad_arena.element_size()))
         self.bucket_of, self.size = {}, [0] * len(self.buckets)
         for i, o in enumerate(offsets):
@@ -52,17 +60,34 @@ class BucketedAllReduce:
 
     def on_ready(self, param_index: int):
         """Parameter `param_index`'s gradient has been enqueued. Launches its bucket when the bucket is complete."""
-        if self.world == 1 or param_index in self.ready:
+        if not self.active or param_index in self.ready:
             return
         self.ready.add(param_index)
         b = self.bucket_of[param_index]
         self.count[b] += 1
         if self.count[b] == self.size[b]:
-            self._launch(b)
+            if self.on_bucket is not None:
+                self.launched.add(b)
+                self.on_bucket(b)
+            else:
+                self._launch(b)
 
-    def _launch(self, b):
+    @property
+    def active(self):
+        return self.world > 1 or self.force
+
+    def launch(self, b):
+        """All-reduce bucket b now, ordered after the current stream only (replay of captured graph segments: the
+        producers of the bucket ran inside graphs launched on the current stream)."""
+        if self.active and b not in self.launched:
+            self._launch(b, plain=True)
+
+    def _launch(self, b, plain=False):
         lo, hi = self.buckets[b]
-        sides = list(self.extra_streams()) if self.extra_streams is not None else []
+        self.launched.add(b)
+        if not self.have_group:
+            return
+        sides = list(self.extra_streams()) if (self.extra_streams is not None and not plain) else []
         if sides:
             # issue from the first side stream after making it wait for the main one and for the other side streams:
             # the collective is then ordered after the gradients written on any of them, and the main stream is not
@@ -76,18 +101,18 @@ class BucketedAllReduce:
         else:
             h = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.handles.append(h)
-        self.launched.add(b)
 
-    def finish(self):
+    def finish(self, plain=False):
         """Call after backward: reduces buckets whose parameters never all reported (unused parameters), waits,
         and turns the sums into means."""
-        if self.world == 1:
+        if not self.active:
             return
         self.early = len(self.launched)
         for b in range(len(self.buckets)):
             if b not in self.launched:
-                self._launch(b)
+                self._launch(b, plain)
         for h in self.handles:
             h.wait()
         self.handles = []
-        self.grad.mul_(1.0 / self.world)
+        if self.world > 1:
+            self.grad.mul_(1.0 / self.world)

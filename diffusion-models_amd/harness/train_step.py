@@ -98,13 +98,14 @@ class TrainStep:
             self.reducer.extra_streams = lambda: [ops.side_stream(dev, 0)] + [
                 s for s in ops.side_streams(dev) if s is not ops.side_stream(dev, 0)]
         self._in_backward = False
+        self._report = False   # backward in progress reports finished gradients to the reducer
+        self._seg = None   # state of a segmented capture in progress (capture_segmented)
         self._sums = ops.SumCollector()
         self._param_index = {id(p): i for i, (_, p) in enumerate(self.arena.params)}
-        if self.world > 1:
-            # gradients that autograd accumulates itself report through this hook; gradients the kernels write in
-            # place report through ops.GRAD_READY (set around backward)
-            for _, p in self.arena.params:
-                p.register_post_accumulate_grad_hook(self._on_grad_ready)
+        # gradients that autograd accumulates itself report through this hook; gradients the kernels write in
+        # place report through ops.GRAD_READY (set around backward); both are no-ops while the reducer is inactive
+        for _, p in self.arena.params:
+            p.register_post_accumulate_grad_hook(self._on_grad_ready)
 
     # ---- bf16 weight mirrors ------------------------------------------------------------------------------
     def _init_weight_mirrors(self):
@@ -162,25 +163,32 @@ class TrainStep:
             pack.bind(w, self.w16[o:o + n], self.w16_t[o:o + n])
 
     def _on_grad_ready(self, p):
-        if self._in_backward:
+        if self._in_backward and self._report:
             i = self._param_index.get(id(p))
             if i is not None:
                 self.reducer.on_ready(i)
 
     # ---- one step ----------------------------------------------------------------------------------------
     def _backward(self, loss, overlap=True):
-        """Backward into the gradient arena. overlap: launch each bucket's all-reduce as soon as it is complete
-        (eager multi-GPU steps); without it the collectives are left to _reduce(), so that this phase contains no
-        communication and can be captured into a HIP graph on every rank."""
+        """Backward into the gradient arena. overlap=True: launch each bucket's all-reduce as soon as it is complete
+        (eager multi-GPU steps); False: the collectives are left to _reduce(), so that this phase contains no
+        communication and can be captured into one HIP graph on every rank; "cut": the phase is being captured
+        (capture_segmented) and the capture is cut into a new graph wherever a bucket becomes complete."""
         self.reducer.begin()
         self._in_backward = True
-        overlapped = self.world > 1 and overlap
+        cut = overlap == "cut"
+        overlapped = self.reducer.active and bool(overlap)
+        self.reducer.on_bucket = self._cut if cut else None
+        self._report = overlapped
         ops.DIRECT_GRADS, ops.GRAD_READY = True, (self._on_grad_ready if overlapped else None)
         ops.SIDE_WGRAD = int(self.side_wgrad)
         # The ordered sums behind bias / GroupNorm-affine / edge-conv gradients run as ONE launch after backward -
         # except when buckets are all-reduced while backward runs: those gradients are spread over every bucket, so
-        # each is then summed where it is produced and its bucket can leave early.
-        ops.PENDING_SUMS = None if overlapped else self._sums
+        # each is then summed where it is produced and its bucket can leave early. A cut capture collects them and
+        # sums what has been collected at every cut.
+        ops.PENDING_SUMS = None if (overlapped and not cut) else self._sums
+        ops.SIDE_TOUCHED.clear()
+        ops.SIDE_KEEP.clear()
         try:
             loss.backward()
         except BaseException:
@@ -188,12 +196,83 @@ class TrainStep:
             raise
         finally:
             ops.DIRECT_GRADS, ops.GRAD_READY, ops.SIDE_WGRAD, ops.PENDING_SUMS = False, None, 0, None
-            self._in_backward = False
-        if self.side_wgrad:
-            # the weight/bias gradient kernels ran on the second stream: join before anything reads the arena
-            for side in ops.side_streams(self.arena.data.device):
-                torch.cuda.current_stream().wait_stream(side)
+            self._in_backward = self._report = False
+            self.reducer.on_bucket = None
+        self._join_sides()
         self._sums.flush()
+
+    def _join_sides(self):
+        """The weight/bias gradient kernels ran on side streams: the current stream waits for every one that was given
+        work since the last join, before anything reads the gradient arena."""
+        cur = torch.cuda.current_stream()
+        for side in list(ops.SIDE_TOUCHED):
+            cur.wait_stream(side)
+        ops.SIDE_TOUCHED.clear()
+        ops.SIDE_KEEP.clear()
+
+    # ---- forward + backward captured as a chain of HIP graphs cut at bucket boundaries ---------------------------
+    def _cut(self, b):
+        """Bucket b is complete (called from inside backward, between two operators, while capturing): close the
+        current graph behind everything that produced the bucket and open the next one. At replay the bucket's
+        all-reduce is issued between the two graphs and runs beside the rest of backward."""
+        seg = self._seg
+        self._join_sides()
+        self._sums.flush()
+        seg["graphs"][-1].capture_end()
+        seg["after"].append([b])
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=seg["pool"], capture_error_mode="relaxed")
+        seg["graphs"].append(g)
+
+    def capture_segmented(self, x=None, label=None, stream=None, loss_fn=None):
+        """Capture forward + backward of one step (train.py:429-440) on (x, label) as a chain of HIP graphs, cut at
+        every point of backward where a gradient bucket of the data-parallel reducer becomes complete; returns the
+        (static) loss tensor. replay_segmented() then replays the chain, issuing each bucket's all-reduce behind the
+        graph that completes it, so the collectives overlap the remaining backward although every kernel launch
+        comes from a graph. With the reducer inactive (one rank, not forced) there is a single graph.
+        loss_fn: a callable returning the loss instead of (x, label) (e.g. loss_given_noise with fixed draws).
+        The caller runs update() (or a graph of it) afterwards."""
+        if self._seg is not None:
+            raise RuntimeError("capture_segmented: a capture is already in progress")
+        stream = stream or torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        seg = self._seg = {"graphs": [], "after": [], "pool": torch.cuda.graph_pool_handle()}
+        with torch.cuda.stream(stream):
+            # (relaxed mode: autograd runs backward on its own thread, so a capture begun on this one is ended
+            # on that one at the first cut, and the last one the other way round)
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=seg["pool"], capture_error_mode="relaxed")
+            seg["graphs"].append(g)
+            try:
+                if loss_fn is not None:
+                    loss = loss_fn()
+                else:
+                    uncond_mask = None
+                    if label is not None:
+                        uncond_mask = torch.bernoulli(self.p_uncond * torch.ones_like(label))
+                    loss = self.scheduler.get_loss(x, self.model, cls=label, uncond_mask=uncond_mask)
+                self._backward(loss, overlap="cut")
+                loss = loss.detach()
+            finally:
+                self._seg = None
+                seg["graphs"][-1].capture_end()
+            seg["after"].append([b for b in range(len(self.reducer.buckets)) if b not in self.reducer.launched])
+        torch.cuda.current_stream().wait_stream(stream)
+        self.segments = (seg["graphs"], seg["after"])
+        return loss
+
+    def replay_segmented(self):
+        """Replay the chain captured by capture_segmented() on the current stream, each bucket's all-reduce issued
+        right behind the graph that completes it; returns when every collective has been enqueued and the current
+        stream waits for all of them (gradients averaged)."""
+        graphs, after = self.segments
+        self.reducer.begin()
+        for g, buckets in zip(graphs, after):
+            g.replay()
+            for b in buckets:
+                self.reducer.launch(b)
+        self.reducer.finish(plain=True)
 
     def _reduce(self):
         """Finish the data-parallel mean of the gradient arena (launches whatever buckets are still outstanding)."""
@@ -249,14 +328,17 @@ class TrainStep:
         self._backward_and_update(loss)
         return loss.detach()
 
-    def step_given_noise(self, x, label, uncond_mask, eps, t):
-        """Same step with the random draws supplied by the caller (parity tests)."""
+    def loss_given_noise(self, x, label, uncond_mask, eps, t):
+        """The loss of scheduler.get_loss with the random draws supplied by the caller."""
         x_t = self.scheduler.diffuse(x, t, eps)
         pred = self.model(x_t, t, cls=label, uncond_mask=uncond_mask)
         if self.scheduler.pred_type == "velocity":
-            loss = ops.mse_loss(pred, eps, x=x, mode=1)
-        else:
-            loss = ops.mse_loss(pred, eps, mode=0)
+            return ops.mse_loss(pred, eps, x=x, mode=1)
+        return ops.mse_loss(pred, eps, mode=0)
+
+    def step_given_noise(self, x, label, uncond_mask, eps, t):
+        """Same step with the random draws supplied by the caller (parity tests)."""
+        loss = self.loss_given_noise(x, label, uncond_mask, eps, t)
         self._backward_and_update(loss)
         return loss.detach(), self.norm.clone()
 

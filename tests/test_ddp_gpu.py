@@ -14,11 +14,13 @@ from tests.parity import PKG, ROOT, TINY_CFG
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q, side_wgrad=1):
+def _worker(rank, world, port, q, side_wgrad=1, segmented=False):
     for p in (ROOT, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
     from tests.parity import det_sd_for
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)   # a stuck rank says where, instead of a silent wait
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,8 +44,29 @@ def _worker(rank, world, port, q, side_wgrad=1):
         t = torch.randint(0, 1000, (B,), generator=g)
         lo, hi = rank * B // world, (rank + 1) * B // world
         before = step.arena.data.clone()
-        loss, gnorm = step.step_given_noise(*(v[lo:hi].to(dev) for v in (x, cls, mask, eps, t)))
-        early = step.reducer.early   # buckets that went out before finish(), i.e. while backward was running
+        args = [v[lo:hi].to(dev) for v in (x, cls, mask, eps, t)]
+        if segmented == "phases":
+            # backward without communication, then every bucket's all-reduce, then the update (the deferred
+            # parameter-gradient sums run as grouped launches, as they do in the segmented form)
+            loss = step.loss_given_noise(*args)
+            step._backward(loss, overlap=False)
+            step._reduce()
+            step._update()
+            loss, gnorm, early = loss.detach(), step.norm.clone(), 0
+        elif not segmented:
+            loss, gnorm = step.step_given_noise(*args)
+            early = step.reducer.early   # buckets that went out before finish(), i.e. while backward was running
+        else:
+            # forward + backward as a chain of HIP graphs cut at the bucket boundaries; the all-reduces are issued
+            # between the replays of the chain's graphs
+            step._backward(step.loss_given_noise(*args), overlap=False)   # warm-up outside capture
+            step.arena.grad.zero_()
+            loss = step.capture_segmented(loss_fn=lambda: step.loss_given_noise(*args))
+            step.replay_segmented()
+            step.update()
+            gnorm = step.norm.clone()
+            early = sum(len(bs) for bs in step.segments[1][:-1])
+            assert world == 1 or len(step.segments[0]) > 2
         torch.cuda.synchronize()
         q.put((rank, float(loss), float(gnorm), (step.arena.data - before).cpu().numpy(), early))
     finally:
@@ -51,10 +74,10 @@ def _worker(rank, world, port, q, side_wgrad=1):
             dist.destroy_process_group()
 
 
-def _run(world, port, side_wgrad=1):
+def _run(world, port, side_wgrad=1, segmented=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, side_wgrad)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, side_wgrad, segmented)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
@@ -86,3 +109,16 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(side_wgrad):
         num = float((delta2 - delta1).norm()) / float(delta1.norm())
         assert num < 0.1, num                              # same AdamW update (bf16 kernels, other batch split: not bit-equal)
     assert torch.equal(two[0][3], two[1][3])               # replicas stay identical
+
+
+def test_two_ranks_segmented_graphs_equal_two_ranks_eager():
+    """The graph-replayed data-parallel step (backward cut into graphs at the bucket boundaries, all-reduces between
+    them) gives bit for bit the update of the eager step in phases (backward, then all collectives, then the update) on
+    the same two half batches."""
+    eager = _run(2, 29641, 1, "phases")
+    seg = _run(2, 29643, 1, True)
+    for (_, le, ne, de, _), (_, ls, ns, ds, early) in zip(eager, seg):
+        assert le == ls and ne == ns
+        assert early > 0
+        assert torch.equal(de, ds)
+    assert torch.equal(seg[0][3], seg[1][3])

@@ -108,6 +108,67 @@ def test_step_in_phases_equals_step():
     assert torch.equal(c.w16, c.arena.data.to(torch.bfloat16))
 
 
+def test_graph_replay_single_and_segmented_equals_eager():
+    """The training step with fixed random draws, three ways: eagerly; forward + backward replayed from one HIP
+    graph; and from a chain of graphs cut at the gradient-bucket boundaries (the form that lets the all-reduces of a
+    multi-GPU run overlap backward while every launch comes from a graph). Gradients after every backward and
+    parameters after every update agree bit for bit: a graph orders the side-stream weight-gradient kernels only by
+    their dependencies, so this also catches a tensor they read being rewritten behind them (autograd accumulating
+    in place into a gradient that was handed back as the residual branch's), and the cuts only move joins of the side
+    stream and flushes of the deferred parameter-gradient sums, each of which has a fixed order."""
+    from dm_hip import ops
+    x, cls = _batch()
+    g = torch.Generator().manual_seed(5)
+    B = x.shape[0]
+    mask = (torch.rand(B, generator=g) < 0.25).float().to(dev())
+    eps = torch.randn(B, 3, 16, 16, generator=g).to(dev())
+    t = torch.randint(0, 1000, (B,), generator=g).to(dev())
+    args = (x, cls, mask, eps, t)
+    a, b, c = _make_step(bucket_mb=1), _make_step(bucket_mb=1), _make_step(bucket_mb=1)
+    c.reducer.force = True          # one rank, no process group: the cuts are made, no collective runs
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    ops.FORCE_REPACK = True
+    graphs = {}
+    try:
+        for s_ in (b, c):
+            with torch.cuda.stream(side):
+                s_._backward(s_.loss_given_noise(*args), overlap=False)    # warm-up outside capture
+                s_.arena.grad.zero_()
+                torch.cuda.synchronize()
+            if s_ is b:
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, stream=side):
+                    s_._backward(s_.loss_given_noise(*args), overlap=False)
+                fb = g1.replay
+            else:
+                s_.capture_segmented(loss_fn=lambda: s_.loss_given_noise(*args), stream=side)
+                fb = s_.replay_segmented
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=side):
+                s_.update()
+            graphs[s_] = (fb, g2)
+    finally:
+        ops.FORCE_REPACK = False
+    torch.cuda.current_stream().wait_stream(side)
+    n_graphs, after = len(c.segments[0]), c.segments[1]
+    assert n_graphs > 2 and sorted(i for bs in after for i in bs) == list(range(len(c.reducer.buckets)))
+    for _ in range(3):
+        a._backward(a.loss_given_noise(*args), overlap=False)
+        graphs[b][0]()
+        graphs[c][0]()
+        torch.cuda.synchronize()
+        assert torch.equal(a.arena.grad, b.arena.grad) and torch.equal(a.arena.grad, c.arena.grad)
+        a.update()
+        graphs[b][1].replay()
+        graphs[c][1].replay()
+        torch.cuda.synchronize()
+        assert torch.equal(a.arena.data, b.arena.data), _worst_params(a, b, 2e-4)
+        assert torch.equal(a.arena.data, c.arena.data), _worst_params(a, c, 2e-4)
+    assert torch.equal(a.ema, c.ema) and torch.equal(a.w16, c.w16) and torch.equal(a.w16_t, c.w16_t)
+    assert float(c.arena.grad.abs().max()) == 0.0
+
+
 def test_captured_graph_survives_larger_eager_calls():
     """Scratch buffers are per call (from the graph's private pool under capture): a forward captured at a small
     batch must replay correctly after larger eager calls have run (train-then-generate flow)."""
