@@ -89,6 +89,10 @@ def main():
         dy = torch.randn(B, Ho, Wo, Cout, device=dev).to(bf)
         dx = torch.empty(B, Hi, Wi, Cin, device=dev, dtype=bf)
         dw = torch.zeros(Cout, k * k, Cin, device=dev)
+        if os.environ.get("DM_BENCH_ZERO") == "1":   # all-zero operands: the clock the chip holds without data toggling
+            for t_ in (x1, x2, w, wt, dy):
+                if t_ is not None:
+                    t_.zero_()
         flops = 2.0 * B * Ho * Wo * Cout * Cin * k * k
         d = ConvDesc(B, H, W, C1, C2, Cout, k, k, stride, pad, ups, 0, Ho, Wo)
         dt = ConvDesc(B, Ho, Wo, Cout, 0, Cin, k, k, stride, pad, 0, 1, Hi, Wi)
