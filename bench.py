@@ -90,7 +90,7 @@ HBM_OPS = {
     "dm_mse_loss_bwd": ("mse_bwd (loss gradient)", lambda a: (16.0 if a[1] else 12.0) * a[5]),
     "dm_sampler_step": ("sampler_step (DDPM/DDIM/Euler update)", lambda a: (16.0 if a[2] else 12.0) * a[10]),
 }
-CONV_OPS = ("dm_conv2d_igemm", "dm_conv2d_wgrad")
+CONV_OPS = ("dm_conv2d_igemm", "dm_conv2d_wgrad", "dm_conv2d_wgrad_group")
 
 
 class AbiTimer:
@@ -111,7 +111,15 @@ class AbiTimer:
 
     def _wrap(self, name, fn):
         def call(*args):
-            if name in CONV_OPS:
+            if name == "dm_conv2d_wgrad_group":     # (items, n, ws, ws_bytes, stream): the layers of one batched call
+                work = nbytes = 0.0
+                for i in range(args[1]):
+                    d = args[0][i].desc
+                    m = d.B * d.Ho * d.Wo
+                    work += 2.0 * m * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
+                    nbytes += 2.0 * (d.B * d.Hs * d.Ws * (d.C1 + d.C2) + m * d.Cout) + 4.0 * d.Cout * d.KH * d.KW * (d.C1 + d.C2)
+                shape = None
+            elif name in CONV_OPS:
                 d = args[0]._obj
                 m = d.B * d.Ho * d.Wo
                 work = 2.0 * m * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
@@ -466,7 +474,11 @@ def main():
             else:
                 get_sampler("euler", n_steps=3, pbar=False).sample(zz, sched, fake)
         summ = ct.summary()
-        ig, wg = summ.get("dm_conv2d_igemm"), summ.get("dm_conv2d_wgrad")
+        ig = summ.get("dm_conv2d_igemm")
+        wg = {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0}
+        for key in ("dm_conv2d_wgrad", "dm_conv2d_wgrad_group"):
+            for k, v in summ.get(key, {}).items():
+                wg[k] += v
         if ig and ig["ms"] > 0:
             achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
             traffic = measured_conv_traffic()

@@ -380,7 +380,7 @@ __device__ __forceinline__ void read_tr(s16x4_t& v, unsigned addr) {
 constexpr int SLAB_FLOATS = 3 * 128 * 64;   // one partial tile of the 3-tap kernel
 
 template <int NST>
-__global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad3_body(const WgradArgs& a, const int logical) {
   constexpr int NT = 512, TCO = 128, TCI = 64;
   using TY = Tile<TCO, NT>;                       // dy tile: 64 pixels x 128 channels
   constexpr int XBYTES = 16384;                   // patch region: up to 128 pixels x 64 channels
@@ -393,8 +393,6 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[TOTAL];
 
   const int per = 3 * a.n_co_tiles * a.n_ci_tiles;
-  const int logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  if (logical >= a.n_blocks) return;
   const int ks = logical / per;
   const int inner = logical - ks * per;
   const int tiles = a.n_co_tiles * a.n_ci_tiles;
@@ -596,19 +594,54 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
   }
 }
 
+// Workgroup b of a grid runs on XCD b % 8: logical block indices are dealt so that each XCD owns a contiguous run
+// (consecutive logical blocks share a pixel slice, i.e. the same dy / input rows, in that XCD's L2).
+__device__ __forceinline__ int xcd_logical_block() {
+  return (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+}
+
+template <int NST>
+__global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
+  const int logical = xcd_logical_block();
+  if (logical >= a.n_blocks) return;
+  wgrad3_body<NST>(a, logical);
+}
+
+// Several layers in one launch: the weight gradients of a backward pass feed nothing but the optimizer, so a few
+// consecutive layers can wait for each other and share the chip. Every launch leaves one partial tile per workgroup
+// (a CU-full of accumulators, 25 MB) whatever the layer, and rounds its workgroup count up to whole rounds of CUs;
+// with G layers per launch each layer is cut into 1/G as many pixel slices, so G times fewer partial tiles are
+// written and summed, the slices are G times longer (fixed costs amortise) and the rounding loss is shared.
+constexpr int WG_MAX = 8;
+struct WgradGroup {
+  WgradArgs it[WG_MAX];
+  int start[WG_MAX + 1];    // first logical block of each layer; start[n] = all blocks
+  int ustart[WG_MAX + 1];   // first unit (wave-sized work item of the slab sum) of each layer, multiples of 4
+  int G[WG_MAX];            // waves sharing a chunk of the slab sum, per layer
+  int n;
+};
+
+template <int NST>
+__global__ __launch_bounds__(512, 1) void conv_wgrad3_group_kernel(WgradGroup g) {
+  const int logical = xcd_logical_block();
+  if (logical >= g.start[g.n]) return;
+  int l = 0;
+  while (l + 1 < g.n && logical >= g.start[l + 1]) ++l;
+  const WgradArgs a = g.it[l];
+  wgrad3_body<NST>(a, logical - g.start[l]);
+}
+
 // Sums the slabs of one tile over the pixel slices and adds the sum to dw, in a fixed order. A wave owns 64
 // consecutive float4s of a tile's slab (a slice is 1 KiB per wave load); G = 1, 2 or 4 waves of a workgroup share such
 // a chunk when there are enough slices - wave g sums slices g, g + G, ... and the partial sums are added in wave
 // order. Lane t of the 64 owns the float4 that thread (q, t2) of the producing workgroups' first wave group held:
 // 4 consecutive output channels of one input channel.
-__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(WgradArgs a, int G) {
-  __shared__ f32x4_t red[4][64];
+// One round of a workgroup: its four waves take units u0 .. u0 + 3 of layer `a` (G the same for all four).
+__device__ __forceinline__ void wgrad3_reduce_round(const WgradArgs& a, const int G, const int u0, f32x4_t (*red)[64]) {
   constexpr int F4 = SLAB_FLOATS / 4, CH = F4 / 64;   // float4s per slab, 64-float4 chunks per slab
   const int per = 3 * a.n_co_tiles * a.n_ci_tiles;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int units = per * CH * G;
-  // a capped grid walks the (chunk, slice group) units; every wave of a workgroup makes the same number of rounds
-  for (int u0 = blockIdx.x * 4; u0 < units; u0 += gridDim.x * 4) {
+  {
     const int unit = u0 + wave;
     const int cid = unit / G, grp = unit - cid * G;      // chunk (over all tiles), slice group
     const bool live = cid < per * CH;
@@ -633,7 +666,7 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(WgradArgs a, int G) 
       if (grp == 0)
         for (int g = 1; g < G; ++g) sum += red[wave + g][lane];
     }
-    if (!live || grp) continue;
+    if (!live || grp) return;
 
     const int q = e >> 8, t2 = e & 255;
     const int tiles = a.n_co_tiles * a.n_ci_tiles;
@@ -646,6 +679,23 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(WgradArgs a, int G) 
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (co + r < a.Cout) a.dw[((size_t)(co + r) * 9 + kh * 3 + t) * a.Cin + ci] += sum[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(WgradArgs a, int G) {
+  __shared__ f32x4_t red[4][64];
+  const int units = 3 * a.n_co_tiles * a.n_ci_tiles * (SLAB_FLOATS / 256) * G;
+  // a capped grid walks the (chunk, slice group) units; every wave of a workgroup makes the same number of rounds
+  for (int u0 = blockIdx.x * 4; u0 < units; u0 += gridDim.x * 4) wgrad3_reduce_round(a, G, u0, red);
+}
+
+__global__ __launch_bounds__(256) void wgrad3_reduce_group_kernel(WgradGroup g) {
+  __shared__ f32x4_t red[4][64];
+  const int units = g.ustart[g.n];
+  int l = 0;
+  for (int u0 = blockIdx.x * 4; u0 < units; u0 += gridDim.x * 4) {   // u0 only grows: l never has to go back
+    while (l + 1 < g.n && u0 >= g.ustart[l + 1]) ++l;
+    wgrad3_reduce_round(g.it[l], g.G[l], u0 - g.ustart[l], red);
   }
 }
 
@@ -671,7 +721,17 @@ static int reduce_grid(long units) {
   return (int)(g < g_dm_wgrad_reduce_cap ? g : g_dm_wgrad_reduce_cap);
 }
 
-static WgradPlan make_plan(const dm_conv_desc* d) {
+static int cu_count() {
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  return n_cu;
+}
+
+// tiles of a layer (everything of the plan but the pixel-axis split)
+static WgradPlan plan_tiles(const dm_conv_desc* d) {
   WgradPlan p;
   const long M = (long)d->B * d->Ho * d->Wo;
   const int Cin = d->C1 + d->C2;
@@ -683,12 +743,25 @@ static WgradPlan make_plan(const dm_conv_desc* d) {
   p.n_co_tiles = dm_cdiv(d->Cout, tco);
   p.n_ci_tiles = Cin / tci;
   p.per = (p.row3 ? 3 : d->KH * d->KW) * p.n_co_tiles * p.n_ci_tiles;
+  return p;
+}
+
+// the split once the number of 64-pixel steps per workgroup is chosen
+static void plan_split(const dm_conv_desc* d, WgradPlan& p, int splitk) {
+  const long M = (long)d->B * d->Ho * d->Wo;
   const int steps_total = dm_cdiv(M, BKM);
-  static const int n_cu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
+  const int tco = (p.wide_co || p.row3) ? 128 : 64, tci = (p.wide_ci && !p.row3) ? 128 : 64;
+  p.rows_per_split = dm_cdiv(steps_total, splitk) * BKM;
+  p.splitk = dm_cdiv(M, p.rows_per_split);
+  p.n_blocks = p.splitk * p.per;
+  p.ws_bytes = (size_t)p.n_blocks * (p.row3 ? SLAB_FLOATS : tco * tci) * sizeof(float);
+}
+
+static WgradPlan make_plan(const dm_conv_desc* d) {
+  WgradPlan p = plan_tiles(d);
+  const long M = (long)d->B * d->Ho * d->Wo;
+  const int steps_total = dm_cdiv(M, BKM);
+  const int n_cu = cu_count();
   // Split the pixel axis to minimise rounds x (steps per workgroup + fixed cost): one workgroup per CU per round,
   // the fixed cost (pipeline fill, partial tile out) counted as OVERHEAD steps.
   const int OVERHEAD = g_dm_wgrad_slab_overhead;
@@ -700,11 +773,40 @@ static WgradPlan make_plan(const dm_conv_desc* d) {
     const long cost = (long)dm_cdiv(p.per * sk, n_cu) * (dm_cdiv(steps_total, sk) + OVERHEAD);
     if (best < 0 || cost < best) { best = cost; splitk = sk; }
   }
-  p.rows_per_split = dm_cdiv(steps_total, splitk) * BKM;
-  p.splitk = dm_cdiv(M, p.rows_per_split);
-  p.n_blocks = p.splitk * p.per;
-  p.ws_bytes = (size_t)p.n_blocks * (p.row3 ? SLAB_FLOATS : tco * tci) * sizeof(float);
+  plan_split(d, p, splitk);
   return p;
+}
+
+// Plans of n three-tap layers that share one launch: one length T (steps per workgroup) for all of them, chosen to
+// minimise rounds x (T + fixed cost) over the summed workgroup count; a layer of S steps is cut into ceil(S / T)
+// slices (at most 128, at least 8 steps each, as in the single-layer plan).
+static void make_group_plan(const dm_conv_desc* const* ds, int n, WgradPlan* plans) {
+  const int n_cu = cu_count(), OVERHEAD = g_dm_wgrad_slab_overhead;
+  int steps[WG_MAX], max_steps = 1;
+  for (int l = 0; l < n; ++l) {
+    plans[l] = plan_tiles(ds[l]);
+    steps[l] = dm_cdiv((long)ds[l]->B * ds[l]->Ho * ds[l]->Wo, BKM);
+    if (steps[l] > max_steps) max_steps = steps[l];
+  }
+  auto split_of = [&](int l, int T) {
+    int sk = dm_cdiv(steps[l], T);
+    const int most = steps[l] / 8 > 0 ? (steps[l] / 8 < 128 ? steps[l] / 8 : 128) : 1;
+    return sk < 1 ? 1 : (sk > most ? most : sk);
+  };
+  int bestT = max_steps;
+  long best = -1;
+  for (int T = max_steps; T >= 8; --T) {   // ties go to the longer slices (fewer partial tiles)
+    long blocks = 0, longest = 0;
+    for (int l = 0; l < n; ++l) {
+      const int sk = split_of(l, T);
+      blocks += (long)plans[l].per * sk;
+      const long len = dm_cdiv(steps[l], sk);
+      if (len > longest) longest = len;
+    }
+    const long cost = dm_cdiv(blocks, n_cu) * (longest + OVERHEAD);
+    if (best < 0 || cost < best) { best = cost; bestT = T; }
+  }
+  for (int l = 0; l < n; ++l) plan_split(ds[l], plans[l], split_of(l, bestT));
 }
 
 extern "C" size_t dm_conv2d_wgrad_ws_bytes(const dm_conv_desc* d) {
@@ -718,26 +820,25 @@ static void launch_single_tap(const WgradArgs& a, const WgradPlan& p, dim3 grid,
   hipLaunchKernelGGL((wgrad_reduce_kernel<TCO, TCI>), dim3(reduce_grid((long)p.per * (TCO * TCI / 256) * G)), dim3(256), 0, st, a, G);
 }
 
-extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, void* ws,
-                               size_t ws_bytes, void* stream) {
-  DM_REQUIRE(d && x1 && dy && dw && ws, DM_ERR_ARG, "dm_conv2d_wgrad: null argument");
+// argument checks of one layer and the fields of WgradArgs that do not depend on the plan
+static int fill_args(const char* who, const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw,
+                     WgradArgs& a) {
+  DM_REQUIRE(d && x1 && dy && dw, DM_ERR_ARG, "%s: null argument", who);
   DM_REQUIRE(d->C1 > 0 && d->C1 % 64 == 0 && d->C2 >= 0 && d->C2 % 64 == 0, DM_ERR_SHAPE,
-             "dm_conv2d_wgrad: input channels (%d, %d) must be multiples of 64", d->C1, d->C2);
-  DM_REQUIRE((d->C2 == 0) == (x2 == nullptr), DM_ERR_ARG, "dm_conv2d_wgrad: x2 and C2 disagree");
-  DM_REQUIRE(d->Cout > 0 && d->Cout % 8 == 0, DM_ERR_SHAPE, "dm_conv2d_wgrad: Cout=%d must be a multiple of 8", d->Cout);
-  DM_REQUIRE(!d->transposed, DM_ERR_UNSUPPORTED, "dm_conv2d_wgrad: transposed descriptor");
-  DM_REQUIRE(d->stride == 1 || d->stride == 2, DM_ERR_UNSUPPORTED, "dm_conv2d_wgrad: stride %d", d->stride);
-  DM_REQUIRE(!(d->ups && d->stride != 1), DM_ERR_UNSUPPORTED, "dm_conv2d_wgrad: fused upsample needs stride 1");
-  DM_REQUIRE(((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dy | (uintptr_t)dw) % 16 == 0, DM_ERR_ARG, "dm_conv2d_wgrad: pointers must be 16-byte aligned");
+             "%s: input channels (%d, %d) must be multiples of 64", who, d->C1, d->C2);
+  DM_REQUIRE((d->C2 == 0) == (x2 == nullptr), DM_ERR_ARG, "%s: x2 and C2 disagree", who);
+  DM_REQUIRE(d->Cout > 0 && d->Cout % 8 == 0, DM_ERR_SHAPE, "%s: Cout=%d must be a multiple of 8", who, d->Cout);
+  DM_REQUIRE(!d->transposed, DM_ERR_UNSUPPORTED, "%s: transposed descriptor", who);
+  DM_REQUIRE(d->stride == 1 || d->stride == 2, DM_ERR_UNSUPPORTED, "%s: stride %d", who, d->stride);
+  DM_REQUIRE(!(d->ups && d->stride != 1), DM_ERR_UNSUPPORTED, "%s: fused upsample needs stride 1", who);
+  DM_REQUIRE(((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dy | (uintptr_t)dw) % 16 == 0, DM_ERR_ARG, "%s: pointers must be 16-byte aligned", who);
   const int Hi = d->Hs << d->ups, Wi = d->Ws << d->ups;
   DM_REQUIRE((Hi + 2 * d->pad - d->KH) / d->stride + 1 == d->Ho && (Wi + 2 * d->pad - d->KW) / d->stride + 1 == d->Wo,
-             DM_ERR_SHAPE, "dm_conv2d_wgrad: in %dx%d k%d s%d p%d does not give out %dx%d", Hi, Wi, d->KH, d->stride, d->pad, d->Ho, d->Wo);
+             DM_ERR_SHAPE, "%s: in %dx%d k%d s%d p%d does not give out %dx%d", who, Hi, Wi, d->KH, d->stride, d->pad, d->Ho, d->Wo);
   const long npix_src = (long)d->B * d->Hs * d->Ws;
   const long M = (long)d->B * d->Ho * d->Wo;
   DM_REQUIRE(npix_src * d->C1 * 2 < 0x7fffffffL && npix_src * d->C2 * 2 < 0x7fffffffL && M * d->Cout * 2 < 0x7fffffffL,
-             DM_ERR_UNSUPPORTED, "dm_conv2d_wgrad: tensor larger than 2 GiB");
-
-  WgradArgs a;
+             DM_ERR_UNSUPPORTED, "%s: tensor larger than 2 GiB", who);
   a.x1 = x1; a.x2 = x2; a.dy = dy; a.dw = dw;
   a.C1 = d->C1; a.C2 = d->C2; a.Cin = d->C1 + d->C2; a.Cout = d->Cout;
   a.B = d->B; a.Hs = d->Hs; a.Ws = d->Ws; a.Hi = Hi; a.Wi = Wi; a.Ho = d->Ho; a.Wo = d->Wo;
@@ -751,23 +852,112 @@ extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void
   a.db_step = BKM / (d->Ho * d->Wo);
   a.dh_step = (BKM % (d->Ho * d->Wo)) / d->Wo;
   a.dw_step = (BKM % (d->Ho * d->Wo)) % d->Wo;
+  return DM_OK;
+}
 
-  const WgradPlan p = make_plan(d);
-  DM_REQUIRE(ws_bytes >= p.ws_bytes, DM_ERR_ARG, "dm_conv2d_wgrad: workspace of %zu bytes, %zu needed", ws_bytes, p.ws_bytes);
-  DM_REQUIRE(((uintptr_t)ws) % 16 == 0, DM_ERR_ARG, "dm_conv2d_wgrad: workspace must be 16-byte aligned");
+static void apply_plan(WgradArgs& a, const WgradPlan& p, void* slabs) {
   a.n_co_tiles = p.n_co_tiles; a.n_ci_tiles = p.n_ci_tiles;
   a.rows_per_split = p.rows_per_split; a.splitk = p.splitk; a.n_blocks = p.n_blocks;
-  a.slabs = (float*)ws;
+  a.slabs = (float*)slabs;
+}
+
+static int reduce_waves(int splitk) { return splitk >= 8 ? 4 : (splitk >= 4 ? 2 : 1); }
+
+static void launch_layer(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   dim3 grid((a.n_blocks + 7) / 8 * 8);
-  hipStream_t st = (hipStream_t)stream;
   if (p.row3) {
     hipLaunchKernelGGL((conv_wgrad3_kernel<4>), grid, dim3(512), 0, st, a);
-    const int G = a.splitk >= 8 ? 4 : (a.splitk >= 4 ? 2 : 1);
+    const int G = reduce_waves(a.splitk);
     hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(reduce_grid((long)p.per * (SLAB_FLOATS / 256) * G)), dim3(256), 0, st, a, G);
   } else if (p.wide_co && p.wide_ci) launch_single_tap<128, 128>(a, p, grid, st);
   else if (p.wide_co) launch_single_tap<128, 64>(a, p, grid, st);
   else if (p.wide_ci) launch_single_tap<64, 128>(a, p, grid, st);
   else launch_single_tap<64, 64>(a, p, grid, st);
+}
+
+extern "C" int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, void* ws,
+                               size_t ws_bytes, void* stream) {
+  WgradArgs a;
+  const int rc = fill_args("dm_conv2d_wgrad", d, x1, x2, dy, dw, a);
+  if (rc) return rc;
+  DM_REQUIRE(ws, DM_ERR_ARG, "dm_conv2d_wgrad: null workspace");
+  const WgradPlan p = make_plan(d);
+  DM_REQUIRE(ws_bytes >= p.ws_bytes, DM_ERR_ARG, "dm_conv2d_wgrad: workspace of %zu bytes, %zu needed", ws_bytes, p.ws_bytes);
+  DM_REQUIRE(((uintptr_t)ws) % 16 == 0, DM_ERR_ARG, "dm_conv2d_wgrad: workspace must be 16-byte aligned");
+  apply_plan(a, p, ws);
+  launch_layer(a, p, (hipStream_t)stream);
+  DM_CHECK_LAUNCH();
+  return DM_OK;
+}
+
+// ---- several layers per call -------------------------------------------------------------------------------------
+// Walks the items in order: runs of up to WG_MAX consecutive three-tap layers share one launch (and one slab-sum
+// launch), every other layer is launched as dm_conv2d_wgrad would. With st == nullptr only the workspace is sized.
+static int wgrad_group(const dm_wgrad_item* items, int n, char* ws, size_t ws_bytes, size_t* need, bool launch, hipStream_t st) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  int i = 0;
+  while (i < n) {
+    int run = 0;
+    while (i + run < n && run < WG_MAX && plan_tiles(&items[i + run].desc).row3) ++run;
+    if (run <= 1) {   // a layer of another kind, or a three-tap layer with no neighbour to share with
+      const dm_wgrad_item& it = items[i];
+      const WgradPlan p = make_plan(&it.desc);
+      const size_t o = take(p.ws_bytes);
+      if (launch) {
+        WgradArgs a;
+        const int rc = fill_args("dm_conv2d_wgrad_group", &it.desc, it.x1, it.x2, it.dy, it.dw, a);
+        if (rc) return rc;
+        DM_REQUIRE(off <= ws_bytes, DM_ERR_ARG, "dm_conv2d_wgrad_group: workspace of %zu bytes is too small", ws_bytes);
+        apply_plan(a, p, ws + o);
+        launch_layer(a, p, st);
+      }
+      i += 1;
+      continue;
+    }
+    const dm_conv_desc* ds[WG_MAX];
+    WgradPlan plans[WG_MAX];
+    for (int l = 0; l < run; ++l) ds[l] = &items[i + l].desc;
+    make_group_plan(ds, run, plans);
+    WgradGroup g;
+    g.n = run;
+    g.start[0] = 0;
+    g.ustart[0] = 0;
+    for (int l = 0; l < run; ++l) {
+      const size_t o = take(plans[l].ws_bytes);
+      g.G[l] = reduce_waves(plans[l].splitk);
+      g.start[l + 1] = g.start[l] + plans[l].n_blocks;
+      g.ustart[l + 1] = g.ustart[l] + (plans[l].per * (SLAB_FLOATS / 256) * g.G[l] + 3) / 4 * 4;
+      if (launch) {
+        const dm_wgrad_item& it = items[i + l];
+        const int rc = fill_args("dm_conv2d_wgrad_group", &it.desc, it.x1, it.x2, it.dy, it.dw, g.it[l]);
+        if (rc) return rc;
+        DM_REQUIRE(off <= ws_bytes, DM_ERR_ARG, "dm_conv2d_wgrad_group: workspace of %zu bytes is too small", ws_bytes);
+        apply_plan(g.it[l], plans[l], ws + o);
+      }
+    }
+    if (launch) {
+      hipLaunchKernelGGL((conv_wgrad3_group_kernel<4>), dim3((g.start[run] + 7) / 8 * 8), dim3(512), 0, st, g);
+      hipLaunchKernelGGL(wgrad3_reduce_group_kernel, dim3(reduce_grid(g.ustart[run])), dim3(256), 0, st, g);
+    }
+    i += run;
+  }
+  *need = off;
+  return DM_OK;
+}
+
+extern "C" size_t dm_conv2d_wgrad_group_ws_bytes(const dm_wgrad_item* items, int n) {
+  size_t need = 0;
+  if (!items || n <= 0 || wgrad_group(items, n, nullptr, 0, &need, false, nullptr) != DM_OK) return 0;
+  return need;
+}
+
+extern "C" int dm_conv2d_wgrad_group(const dm_wgrad_item* items, int n, void* ws, size_t ws_bytes, void* stream) {
+  DM_REQUIRE(items && n > 0 && ws, DM_ERR_ARG, "dm_conv2d_wgrad_group: null argument or no items");
+  DM_REQUIRE(((uintptr_t)ws) % 256 == 0, DM_ERR_ARG, "dm_conv2d_wgrad_group: workspace must be 256-byte aligned");
+  size_t need = 0;
+  const int rc = wgrad_group(items, n, (char*)ws, ws_bytes, &need, true, (hipStream_t)stream);
+  if (rc) return rc;
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

@@ -41,6 +41,11 @@ class SumItem(ctypes.Structure):
                 ("out0", c_void_p), ("out1", c_void_p), ("out2", c_void_p), ("dual0", c_void_p)]
 
 
+class WgradItem(ctypes.Structure):
+    """dm_wgrad_item: one layer of a batched weight-gradient call."""
+    _fields_ = [("desc", ConvDesc), ("x1", c_void_p), ("x2", c_void_p), ("dy", c_void_p), ("dw", c_void_p)]
+
+
 class WtItem(ctypes.Structure):
     """dm_wt_item: one weight of a batched forward->data-gradient re-layout (element offset, dims, first tile)."""
     _fields_ = [("offset", c_long), ("Cout", c_int), ("T", c_int), ("Cin", c_int), ("tile_begin", c_int)]
@@ -53,6 +58,8 @@ _SIGNATURES = {
     "dm_conv2d_igemm": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "dm_conv2d_wgrad_ws_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "dm_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, ctypes.c_size_t, P]),
+    "dm_conv2d_wgrad_group_ws_bytes": (ctypes.c_size_t, [P, c_int]),
+    "dm_conv2d_wgrad_group": (c_int, [P, c_int, P, ctypes.c_size_t, P]),
     "dm_pack_conv_weight": (c_int, [P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P, P, P]),
     "dm_transpose_conv_weights": (c_int, [P, P, P, c_int, c_int, P]),
     "dm_colsum_ws_floats": (c_long, [c_long, c_int]),

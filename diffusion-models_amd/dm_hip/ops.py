@@ -9,7 +9,7 @@ import ctypes
 import torch
 from torch.autograd import Function
 
-from . import ConvDesc, GnDesc, LinearItem, SumItem, check, lib
+from . import ConvDesc, GnDesc, LinearItem, SumItem, WgradItem, check, lib
 
 BF16 = torch.bfloat16
 CL = torch.channels_last
@@ -77,6 +77,71 @@ class SumCollector:
 # gradients are collected there instead of being launched one by one; whoever sets it calls flush() after backward
 # (after joining the side streams) and before anything reads those gradients.
 PENDING_SUMS = None
+
+
+class WgradCollector:
+    """Deferred convolution weight gradients (dm_wgrad_item): with DIRECT_GRADS on, a convolution's backward files its
+    weight gradient here instead of launching it, and every `group` layers (and at flush()) they run as ONE call of
+    dm_conv2d_wgrad_group on the side stream - fewer, longer pixel slices per layer, fewer partial tiles. The operands
+    (dy and the saved inputs) are kept alive until the launch; GRAD_READY is told about the parameters at the launch.
+    flush() must be called before the side streams are joined."""
+
+    def __init__(self, group=6, tail=2):
+        self.group = group
+        self.tail = tail          # group size once fewer than `group` layers of the pass are still to come
+        self.expected = 0         # layers one backward pass files here (0: unknown); set by begin_pass()
+        self.seen = 0
+        self.items = (WgradItem * 64)()
+        self.count = 0
+        self.keep = []      # operand tensors of the pending items
+        self.params = []
+        self.pending_ids = set()   # id() of the parameters whose gradient is filed here and not launched yet
+
+    def add(self, desc, x1, x2, dy, dw, param):
+        it = self.items[self.count]
+        it.desc, it.x1, it.x2, it.dy, it.dw = desc, x1.data_ptr(), _p(x2), dy.data_ptr(), dw.data_ptr()
+        self.count += 1
+        self.keep += [t for t in (x1, x2, dy) if t is not None]
+        self.params.append(param)
+        self.pending_ids.add(id(param))
+        self.seen += 1
+
+    def begin_pass(self, expected=0):
+        """Before a backward pass; expected: how many layers it will file (lets the last launches be small: whatever
+        is launched after the last data-gradient kernel has nothing left to run beside)."""
+        self.expected, self.seen = expected, 0
+
+    def flush_if_full(self):
+        """Called by an operator after its own last launch (flush() may end a HIP-graph capture through GRAD_READY,
+        and a side stream forked by the operator belongs to the capture that was open then)."""
+        limit = self.group
+        if self.expected and self.expected - self.seen < self.group:
+            limit = self.tail
+        if self.count >= min(limit, len(self.items)):
+            self.flush()
+
+    def flush(self):
+        if not self.count:
+            return
+        n, self.count = self.count, 0
+        keep, self.keep = self.keep, []
+        params, self.params = self.params, []
+        self.pending_ids.clear()
+        st, stream_w = _param_stream(keep, True)
+        nbytes = lib.dm_conv2d_wgrad_group_ws_bytes(self.items, n)
+        ws = _scratch(keep[0].device, (nbytes + 3) // 4 + 64, stream_w)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        check(lib.dm_conv2d_wgrad_group(self.items, n, base, nbytes, st))
+        for prm in params:
+            _grad_done(prm)
+
+    def drop(self):
+        self.count, self.keep, self.params = 0, [], []
+        self.pending_ids.clear()
+
+
+# When set (a WgradCollector) and DIRECT_GRADS is on, convolution weight gradients are collected there.
+PENDING_WGRADS = None
 
 
 def _deferred(direct, *tensors):
@@ -298,13 +363,16 @@ class _ConvFn(Function):
             d = _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, 0, Ho, Wo)
             # split-K partial tiles go through a scratch workspace (no float atomics, order-independent sums),
             # allocated on the stream that runs the kernel
-            ws_bytes = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(d))
-            ws = _scratch(dy.device, (ws_bytes + 3) // 4, stream_w)
-            check(lib.dm_conv2d_wgrad(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(),
-                                      ws.data_ptr(), ws.numel() * 4, st_w))
-            if wsink is not None:
-                done.append(wparam)
+            if wsink is not None and PENDING_WGRADS is not None:
+                PENDING_WGRADS.add(d, x1, x2, dy, dwf, wparam)   # launched with its neighbours; reports the parameter then
             else:
+                ws_bytes = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(d))
+                ws = _scratch(dy.device, (ws_bytes + 3) // 4, stream_w)
+                check(lib.dm_conv2d_wgrad(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(),
+                                          ws.data_ptr(), ws.numel() * 4, st_w))
+                if wsink is not None:
+                    done.append(wparam)
+            if wsink is None:
                 dw = dwf.permute(0, 3, 1, 2)
                 if weight.dim() == 2:
                     dw = dw.reshape(Cout, Cin)
@@ -336,8 +404,10 @@ class _ConvFn(Function):
         # report, and the side stream forked above belongs to the capture that was open then
         for prm in done:
             _grad_done(prm)
+        if PENDING_WGRADS is not None:
+            PENDING_WGRADS.flush_if_full()
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
-        if dres is not None and stream_w is not None:
+        if dres is not None and (stream_w is not None or SIDE_WGRAD):
             SIDE_KEEP.append(dy)
         return dx1, dx2, dw, db, dres, None, None, None, None, None, None
 

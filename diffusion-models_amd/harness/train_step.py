@@ -14,6 +14,7 @@ the order gradients become ready) while backward is still running.
 """
 import ctypes
 import math
+import os
 from typing import Optional
 
 import torch
@@ -69,7 +70,7 @@ class FlatArena:
 class TrainStep:
     def __init__(self, model, scheduler, lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2,
                  clip_grad_norm: Optional[float] = 1.0, use_ema=True, ema_inv_gamma=1.0, ema_power=0.75,
-                 ema_max_decay=0.9999, p_uncond=0.2, bucket_mb=25, process_group=None, side_wgrad=None):
+                 ema_max_decay=0.9999, p_uncond=0.2, bucket_mb=25, process_group=None, side_wgrad=None, wgrad_group=None):
         self.model, self.scheduler = model, scheduler
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.clip = float(clip_grad_norm) if clip_grad_norm else 0.0
@@ -101,11 +102,24 @@ class TrainStep:
         self._report = False   # backward in progress reports finished gradients to the reducer
         self._seg = None   # state of a segmented capture in progress (capture_segmented)
         self._sums = ops.SumCollector()
+        if wgrad_group is None:
+            # Layers per weight-gradient launch (<= 1: every layer launches its own, the default). Measured on the
+            # CIFAR UNet at batch 128: groups of 4-8 cut the weight-gradient kernels' own time by 12 % (fewer partial
+            # tiles, fuller rounds of workgroups) but the step got 5 % SLOWER - bunched into a few long launches the
+            # MFMA-bound weight gradients no longer interleave with the HBM-bound GroupNorm kernels of the main
+            # stream, which is where the second stream earns its keep.
+            wgrad_group = int(os.environ.get("DM_WGRAD_GROUP", "0"))
+        self._wgrads = None
+        if wgrad_group > 1:
+            self._wgrads = ops.WgradCollector(group=wgrad_group, tail=int(os.environ.get("DM_WGRAD_TAIL", "2")))
+            from modeling.layers import Linear
+            # every Conv2d / token Linear runs once per forward, so files one weight gradient per backward
+            self._n_wgrads = sum(isinstance(m, (Conv2d, Linear)) for m in model.modules())
         self._param_index = {id(p): i for i, (_, p) in enumerate(self.arena.params)}
         # gradients that autograd accumulates itself report through this hook; gradients the kernels write in
         # place report through ops.GRAD_READY (set around backward); both are no-ops while the reducer is inactive
         for _, p in self.arena.params:
-            p.register_post_accumulate_grad_hook(self._on_grad_ready)
+            p.register_post_accumulate_grad_hook(self._on_accumulated)
 
     # ---- bf16 weight mirrors ------------------------------------------------------------------------------
     def _init_weight_mirrors(self):
@@ -162,6 +176,14 @@ class TrainStep:
         for pack, w, o, n in self._bound:
             pack.bind(w, self.w16[o:o + n], self.w16_t[o:o + n])
 
+    def _on_accumulated(self, p):
+        """Autograd's post-accumulate hook. It also fires for a parameter whose operator returned no gradient because
+        a kernel writes it in place - harmless once that kernel has been enqueued, but a convolution weight filed with
+        the weight-gradient collector has no kernel yet: the collector reports it when it launches."""
+        if self._wgrads is not None and id(p) in self._wgrads.pending_ids:
+            return
+        self._on_grad_ready(p)
+
     def _on_grad_ready(self, p):
         if self._in_backward and self._report:
             i = self._param_index.get(id(p))
@@ -187,15 +209,24 @@ class TrainStep:
         # each is then summed where it is produced and its bucket can leave early. A cut capture collects them and
         # sums what has been collected at every cut.
         ops.PENDING_SUMS = None if (overlapped and not cut) else self._sums
+        # convolution weight gradients run several layers per launch
+        ops.PENDING_WGRADS = self._wgrads
+        if self._wgrads is not None:
+            self._wgrads.begin_pass(self._n_wgrads)
         ops.SIDE_TOUCHED.clear()
         ops.SIDE_KEEP.clear()
         try:
             loss.backward()
+            if self._wgrads is not None:
+                self._wgrads.flush()    # the layers still waiting for neighbours (may complete buckets / cut)
         except BaseException:
             self._sums.count, self._sums.keep = 0, []   # a failed backward leaves nothing to sum
+            if self._wgrads is not None:
+                self._wgrads.drop()
             raise
         finally:
             ops.DIRECT_GRADS, ops.GRAD_READY, ops.SIDE_WGRAD, ops.PENDING_SUMS = False, None, 0, None
+            ops.PENDING_WGRADS = None
             self._in_backward = self._report = False
             self.reducer.on_bucket = None
         self._join_sides()

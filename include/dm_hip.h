@@ -95,6 +95,22 @@ size_t dm_conv2d_wgrad_ws_bytes(const dm_conv_desc* d);
 int dm_conv2d_wgrad(const dm_conv_desc* d, const void* x1, const void* x2, const void* dy, float* dw, void* ws,
                     size_t ws_bytes, void* stream);
 
+/* The weight gradients of several layers in one call (the same sums as n calls of dm_conv2d_wgrad, bit for bit per
+ * layer given the same pixel split): runs of up to 8 consecutive 3x3 / stride-1 layers share one launch, so each layer
+ * is cut into fewer, longer pixel slices and fewer partial tiles are written and summed. ws: 256-byte aligned scratch of
+ * at least dm_conv2d_wgrad_group_ws_bytes(items, n) bytes. Nothing in the reference batches layers: autograd computes
+ * these gradients layer by layer inside loss.backward() (train.py:440); they feed only the optimizer (train.py:447),
+ * which is what allows a few layers to wait for each other. */
+typedef struct {
+  dm_conv_desc desc;
+  const void* x1;
+  const void* x2;   /* null when desc.C2 == 0 */
+  const void* dy;
+  float* dw;        /* fp32 [Cout][KH*KW][C1+C2], ACCUMULATES */
+} dm_wgrad_item;
+size_t dm_conv2d_wgrad_group_ws_bytes(const dm_wgrad_item* items, int n);
+int dm_conv2d_wgrad_group(const dm_wgrad_item* items, int n, void* ws, size_t ws_bytes, void* stream);
+
 /* fp32 parameter [Cout][Cin][KH][KW] with arbitrary element strides -> bf16 [Cout][T][Cin] (w_fwd) and
  * bf16 [Cin][T][Cout] (w_dgrad); either output may be null */
 int dm_pack_conv_weight(const float* w, long s_co, long s_ci, long s_kh, long s_kw, int Cout, int Cin, int KH,

@@ -61,6 +61,26 @@ def test_training_step_is_bitwise_reproducible():
         assert torch.equal(b.ema, a.ema) and torch.equal(b.w16, a.w16) and torch.equal(b.w16_t, a.w16_t)
 
 
+def test_step_with_grouped_weight_gradients():
+    """wgrad_group=4: convolution weight gradients are filed with a collector and launched four layers at a time
+    (dm_conv2d_wgrad_group; off by default). Same step as with one launch per layer up to the order of the fp32 sums,
+    and reproducible bit for bit."""
+    x, cls = _batch()
+    runs = []
+    for group in (0, 4, 4):
+        s_ = _make_step(wgrad_group=group)
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(77)
+        losses = [float(s_.step(x, cls)) for _ in range(2)]
+        torch.cuda.synchronize()
+        runs.append((s_, losses))
+    (a, la), (b, lb), (c, lc) = runs
+    assert lb == lc and torch.equal(b.arena.data, c.arena.data) and torch.equal(b.ema, c.ema)
+    assert abs(la[0] - lb[0]) < 1e-6 * abs(la[0])
+    moved = (a.arena.data - _make_step().arena.data).norm()
+    assert float((a.arena.data - b.arena.data).norm()) < 2e-2 * float(moved), _worst_params(a, b, 2e-4)
+
+
 def test_step_in_phases_equals_step():
     """forward_backward -> reduce -> update (the form whose local phases are captured as two HIP graphs on more than
     one GPU) is the same step as step(): same random draws, bit-identical parameters afterwards, eagerly and replayed."""

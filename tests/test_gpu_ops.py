@@ -167,6 +167,74 @@ def test_conv2d_wgrad_workspace(B, C1, C2, Cout, H, W, ups, k, stride):
     assert lib.dm_conv2d_wgrad(ctypes.byref(desc), p(x1), p(x2), p(dy), out.data_ptr(), small.data_ptr(), 64, st) != 0
 
 
+def test_conv2d_wgrad_group():
+    """Several layers' weight gradients in one call: runs of 3x3 / stride-1 layers share one launch (other pixel
+    splits than the one-layer calls choose), other layers in the list go out one by one. Every layer against torch's
+    fp32 conv weight gradient on the same bf16-rounded operands and against the one-layer entry point; accumulating,
+    independent of the workspace's contents, bit-identical from run to run."""
+    import ctypes
+    from dm_hip import ConvDesc, WgradItem, check, lib
+    d_ = dev()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(99)
+    bf = torch.bfloat16
+    #          B, C1, C2, Cout, H, W, ups, k, stride
+    layers = [(32, 128, 0, 128, 8, 8, 0, 3, 1),
+              (32, 64, 64, 192, 8, 8, 0, 3, 1),      # two sources, ragged output-channel tile
+              (8, 128, 0, 64, 8, 8, 1, 3, 1),        # fused upsample: 16x16 output
+              (8, 64, 0, 128, 16, 16, 0, 1, 1),      # 1x1: not a three-tap layer, splits the run
+              (16, 64, 0, 64, 32, 32, 0, 3, 1),
+              (4, 64, 0, 64, 28, 28, 0, 3, 1),       # width 28: single-tap kernel on a 3x3 layer
+              (8, 256, 0, 128, 16, 16, 0, 3, 1)] + [(4, 64, 0, 64, 8, 8, 0, 3, 1)] * 9   # a run longer than 8
+    items = (WgradItem * len(layers))()
+    keep, wants, bases, singles = [], [], [], []
+    for i, (B, C1, C2, Cout, H, W, ups, k, stride) in enumerate(layers):
+        pad = (k - 1) // 2
+        Hi, Wi = H << ups, W << ups
+        Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
+        Cin = C1 + C2
+        x1c = torch.randn(B, H, W, C1, generator=g).to(bf)
+        x2c = torch.randn(B, H, W, C2, generator=g).to(bf) if C2 else None
+        dyc = torch.randn(B, Ho, Wo, Cout, generator=g).to(bf)
+        x1, x2, dy = x1c.to(d_), (x2c.to(d_) if C2 else None), dyc.to(d_)
+        xin = (x1c if x2c is None else torch.cat([x1c, x2c], -1)).float().permute(0, 3, 1, 2)
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        wz = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+        F.conv2d(xin, wz, None, stride=stride, padding=pad).backward(dyc.float().permute(0, 3, 1, 2))
+        wants.append(wz.grad.permute(0, 2, 3, 1).reshape(-1))
+        base = torch.randn(Cout * k * k * Cin + 64, generator=g).to(d_)
+        bases.append(base)
+        desc = ConvDesc(B, H, W, C1, C2, Cout, k, k, stride, pad, ups, 0, Ho, Wo)
+        it = items[i]
+        it.desc, it.x1, it.x2, it.dy = desc, x1.data_ptr(), (x2.data_ptr() if C2 else None), dy.data_ptr()
+        keep += [x1, x2, dy]
+        nb = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(desc))
+        ws1 = torch.empty(nb // 4, device=d_)
+        one = base.clone()
+        check(lib.dm_conv2d_wgrad(ctypes.byref(desc), x1.data_ptr(), it.x2, dy.data_ptr(), one.data_ptr(), ws1.data_ptr(), nb, st))
+        singles.append(one)
+    nbytes = lib.dm_conv2d_wgrad_group_ws_bytes(items, len(layers))
+    assert nbytes > 0 and nbytes % 256 == 0
+    runs = []
+    for fill in (0.0, float("nan")):
+        ws = torch.full((nbytes // 4 + 64,), fill, device=d_)
+        outs = [b.clone() for b in bases]
+        for i, o in enumerate(outs):
+            items[i].dw = o.data_ptr()
+        check(lib.dm_conv2d_wgrad_group(items, len(layers), (ws.data_ptr() + 255) // 256 * 256, nbytes, st))
+        runs.append(outs)
+    torch.cuda.synchronize()
+    for i in range(len(layers)):
+        a, b = runs[0][i], runs[1][i]
+        assert torch.equal(a, b), i
+        assert torch.equal(a[-64:], bases[i][-64:]), i
+        assert rel_err(a[:-64] - bases[i][:-64], wants[i]) < 2e-5, i
+        assert rel_err(a[:-64] - bases[i][:-64], singles[i][:-64] - bases[i][:-64]) < 2e-5, i
+    assert torch.equal(runs[0][3], singles[3]) and torch.equal(runs[0][5], singles[5])   # launched as the one-layer call does
+    assert lib.dm_conv2d_wgrad_group(items, len(layers), (ws.data_ptr() + 255) // 256 * 256, 1024, st) != 0
+
+
 def test_parameter_gradient_kernels_are_bitwise_reproducible():
     """Every parameter-gradient reduction (GroupNorm affine and upstream bias, conv bias column sums, edge-conv
     weights, class table) sums in a fixed order: two runs on the same inputs must agree bit for bit."""
