@@ -4,6 +4,8 @@
 // accesses on the feature side and the (tiny) weights held in LDS.
 #include "dm_common.h"
 
+extern int g_dm_edge_mfma;
+
 namespace {
 
 constexpr int NT = 256;
@@ -109,6 +111,197 @@ __global__ __launch_bounds__(NT) void big_to_small_kernel(const bf16_t* __restri
       float t = acc[co];
       for (int o = VP >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
       if (ok && v == 0) y[((size_t)b * Cs + co) * H * W + h * W + x] = t + (bias ? bias[co] : 0.f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Matrix-core forms of the two kernels above. The VALU forms spend ~400 instructions per (pixel, 8 channels) on 216
+// FMAs, 54 LDS weight reads and 27 bounds-checked loads and run at a fifth of the HBM rate of their one big tensor.
+// Here the small side is an im2col row of K = 9 * Cs <= 36 values per pixel, i.e. one (or two) 16x16x32 k-steps.
+// fp32 operands keep their precision: each is split into two bf16 (v = hi + lo, |lo| <= 2^-9 |v|) and the product
+// is hi*hi + lo*hi + hi*lo, exact bf16 products summed in fp32 (relative error 2^-16 instead of bf16's 2^-9).
+__device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
+  hi = (bf16_t)v;
+  lo = (bf16_t)(v - (float)hi);
+}
+
+// image -> features. D[i][n] = sum_k A[i][k] B[k][n] with i = feature channel (A: the weights, held in registers for
+// the whole kernel), n = pixel (B: the pixel's im2col row, gathered by the lane that owns the pixel: lane l holds
+// k = 8 (l / 16) .. + 7 of pixel l % 16); the lane then owns 4 consecutive channels of its pixel (an 8-byte store).
+// One workgroup = (pixel chunk, 128-channel chunk); NTC = 16-channel tiles per workgroup (1, 2, 4 or 8).
+template <int CS, int NTC>
+__global__ __launch_bounds__(NT) void small_to_big_mfma_kernel(const float* __restrict__ small, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, bf16_t* __restrict__ big,
+                                                               int B, int H, int W, int Cb, int sg, int w_big_major,
+                                                               int pix_per_block) {
+  constexpr int K = CS * 9, KS = (K + 31) / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int c0 = blockIdx.y * (NTC * 16);
+  const int HW = H * W, M = B * HW;
+  bf16x8_t ahi[KS][NTC], alo[KS][NTC];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+      const int cb = c0 + 16 * t + li;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = ks * 32 + 8 * g + e;
+        float v = 0.f;
+        if (k < K && cb < Cb) {
+          const int cs = k / 9, tap = k - cs * 9;
+          v = w_big_major ? w[(cb * CS + cs) * 9 + tap] : w[(cs * Cb + cb) * 9 + tap];
+        }
+        bf16_t h, l;
+        split_bf16(v, h, l);
+        ahi[ks][t][e] = h;
+        alo[ks][t][e] = l;
+      }
+    }
+  f32x4_t bv[NTC];
+#pragma unroll
+  for (int t = 0; t < NTC; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cb = c0 + 16 * t + 4 * g + r;
+      bv[t][r] = (bias && cb < Cb) ? bias[cb] : 0.f;
+    }
+  // this lane's 8 (or 16) im2col entries: channel plane offset, row / column step (0 beyond K)
+  int koff[KS][8], kdh[KS][8], kdw[KS][8];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = ks * 32 + 8 * g + e;
+      const int cs = k / 9, tap = k - cs * 9, kh = tap / 3, kw = tap - kh * 3;
+      kdh[ks][e] = k < K ? sg * (kh - 1) : 4;   // 4: never inside the image's 3x3 neighbourhood test below
+      kdw[ks][e] = sg * (kw - 1);
+      koff[ks][e] = cs * HW;
+    }
+  const int m_begin = blockIdx.x * pix_per_block, m_end = min(M, m_begin + pix_per_block);
+  for (int m0 = m_begin + 16 * wave; m0 < m_end; m0 += 64) {
+    const int m = m0 + li;
+    const bool live = m < m_end;
+    const int mm = live ? m : m_end - 1;
+    const int b = mm / HW, r0 = mm - b * HW, h = r0 / W, x = r0 - h * W;
+    const float* sp = small + (size_t)b * CS * HW;
+    bf16x8_t bhi[KS], blo[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ih = h + kdh[ks][e], iw = x + kdw[ks][e];
+        float v = 0.f;
+        if (kdh[ks][e] != 4 && ih >= 0 && ih < H && iw >= 0 && iw < W) v = sp[koff[ks][e] + ih * W + iw];
+        bf16_t hh, ll;
+        split_bf16(v, hh, ll);
+        bhi[ks][e] = hh;
+        blo[ks][e] = ll;
+      }
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+      f32x4_t acc = bv[t];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[ks][t], bhi[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[ks][t], blo[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[ks][t], bhi[ks], acc, 0, 0, 0);
+      }
+      const int cb = c0 + 16 * t + 4 * g;
+      if (live && cb < Cb) {
+        const bf16x4_t o = {(bf16_t)acc[0], (bf16_t)acc[1], (bf16_t)acc[2], (bf16_t)acc[3]};
+        *(bf16x4_t*)(big + (size_t)m * Cb + cb) = o;
+      }
+    }
+  }
+}
+
+// features -> image. D[i][n] with i = image channel (A: the weights as hi/lo bf16 fragments in LDS, rows >= Cs are
+// zero), n = pixel (B: 16 bytes of the feature row of the pixel's tap neighbour, straight from global memory - each
+// row is read by 9 taps and comes from cache for 8 of them). k-steps: (tap, 32-channel block). Lanes 0..15 end up
+// with the Cs outputs of their pixel: consecutive pixels of one image plane, a coalesced fp32 store per channel.
+template <int CS>
+__global__ __launch_bounds__(NT) void big_to_small_mfma_kernel(const bf16_t* __restrict__ big, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                               int H, int W, int Cb, int pix_per_block) {
+  extern __shared__ __attribute__((aligned(16))) char wl_raw[];   // [kstep][hi | lo][co * 4 + g] fragments of 16 bytes
+  bf16x8_t* wl = (bf16x8_t*)wl_raw;
+  const int nblk = Cb >> 5, nks = 9 * nblk;
+  for (int i = threadIdx.x; i < nks * CS * 4; i += NT) {
+    const int s = i / (CS * 4), rr = i - s * (CS * 4), co = rr >> 2, gg = rr & 3;
+    const int tap = s / nblk, blk = s - tap * nblk;
+    bf16x8_t hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bf16_t hh, ll;
+      split_bf16(w[(co * Cb + blk * 32 + 8 * gg + e) * 9 + tap], hh, ll);
+      hi[e] = hh;
+      lo[e] = ll;
+    }
+    wl[(s * 2 + 0) * (CS * 4) + rr] = hi;
+    wl[(s * 2 + 1) * (CS * 4) + rr] = lo;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int HW = H * W, M = B * HW;
+  const bool arow = li < CS;
+  const int aslot = (arow ? li : 0) * 4 + g;
+  const bf16x8_t zero8 = {};
+  const int m_begin = blockIdx.x * pix_per_block, m_end = min(M, m_begin + pix_per_block);
+  for (int m0 = m_begin + 32 * wave; m0 < m_end; m0 += 128) {   // two groups of 16 pixels per wave and round
+    int pb[2], ph[2], px[2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + 16 * u + li;
+      live[u] = m < m_end;
+      const int mm = live[u] ? m : m_end - 1;
+      pb[u] = mm / HW;
+      const int r0 = mm - pb[u] * HW;
+      ph[u] = r0 / W;
+      px[u] = r0 - ph[u] * W;
+    }
+    f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    // k-steps in batches of 4 32-channel blocks: the batch's 8 feature loads are issued together (a wave has nothing
+    // else to hide their latency under), then its 16 MFMAs run
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const bf16_t* src[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ih = ph[u] + kh - 1, iw = px[u] + kw - 1;
+        const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+        src[u] = ok ? big + ((size_t)(pb[u] * H + ih) * W + iw) * Cb + 8 * g : nullptr;
+      }
+      for (int blk0 = 0; blk0 < nblk; blk0 += 4) {
+        bf16x8_t f[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            f[q][u] = (src[u] && blk0 + q < nblk) ? *(const bf16x8_t*)(src[u] + (blk0 + q) * 32) : zero8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int s = tap * nblk + min(blk0 + q, nblk - 1);   // (a block beyond the end multiplies zeros)
+          const bf16x8_t a_hi = arow ? wl[(s * 2 + 0) * (CS * 4) + aslot] : zero8;
+          const bf16x8_t a_lo = arow ? wl[(s * 2 + 1) * (CS * 4) + aslot] : zero8;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, f[q][u], acc[u], 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, f[q][u], acc[u], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (live[u]) {
+#pragma unroll
+          for (int co = 0; co < CS; ++co)
+            y[((size_t)pb[u] * CS + co) * HW + ph[u] * W + px[u]] = acc[u][co] + (bias ? bias[co] : 0.f);
+        }
     }
   }
 }
@@ -398,6 +591,36 @@ int check_edge(const char* who, int B, int Cs, int H, int W, int Cb) {
   return DM_OK;
 }
 
+template <int CS>
+void launch_small_to_big_mfma(const float* small, const float* w, const float* bias, bf16_t* big, int B, int H, int W, int Cb,
+                              int sg, int w_big_major, hipStream_t st) {
+  const int M = B * H * W, ppb = 512;
+  const int ntc = Cb >= 128 ? 8 : Cb / 16;
+  const dim3 grid(dm_cdiv(M, ppb), dm_cdiv(Cb, ntc * 16));
+  switch (ntc) {
+    case 8: hipLaunchKernelGGL((small_to_big_mfma_kernel<CS, 8>), grid, dim3(NT), 0, st, small, w, bias, big, B, H, W, Cb, sg, w_big_major, ppb); break;
+    case 4: hipLaunchKernelGGL((small_to_big_mfma_kernel<CS, 4>), grid, dim3(NT), 0, st, small, w, bias, big, B, H, W, Cb, sg, w_big_major, ppb); break;
+    case 2: hipLaunchKernelGGL((small_to_big_mfma_kernel<CS, 2>), grid, dim3(NT), 0, st, small, w, bias, big, B, H, W, Cb, sg, w_big_major, ppb); break;
+    default: hipLaunchKernelGGL((small_to_big_mfma_kernel<CS, 1>), grid, dim3(NT), 0, st, small, w, bias, big, B, H, W, Cb, sg, w_big_major, ppb); break;
+  }
+}
+
+void launch_small_to_big(const float* small, const float* w, const float* bias, bf16_t* big, int B, int Cs, int H, int W,
+                         int Cb, int sg, int w_big_major, hipStream_t st) {
+  if (g_dm_edge_mfma && Cb % 16 == 0) {
+    switch (Cs) {
+      case 1: launch_small_to_big_mfma<1>(small, w, bias, big, B, H, W, Cb, sg, w_big_major, st); break;
+      case 2: launch_small_to_big_mfma<2>(small, w, bias, big, B, H, W, Cb, sg, w_big_major, st); break;
+      case 3: launch_small_to_big_mfma<3>(small, w, bias, big, B, H, W, Cb, sg, w_big_major, st); break;
+      default: launch_small_to_big_mfma<4>(small, w, bias, big, B, H, W, Cb, sg, w_big_major, st); break;
+    }
+    return;
+  }
+  const int M = B * H * W, ppb = 128;
+  hipLaunchKernelGGL(small_to_big_kernel, dim3(dm_cdiv(M, ppb)), dim3(NT), Cs * 9 * Cb * 4, st, small, w, bias, big, B, Cs,
+                     H, W, Cb, sg, w_big_major, ppb);
+}
+
 }  // namespace
 
 extern "C" int dm_in_conv_fwd(const float* x, const float* w, const float* bias, void* y, int B, int Cs, int H, int W,
@@ -405,9 +628,7 @@ extern "C" int dm_in_conv_fwd(const float* x, const float* w, const float* bias,
   int rc = check_edge("dm_in_conv_fwd", B, Cs, H, W, Cb);
   if (rc) return rc;
   DM_REQUIRE(x && w && y, DM_ERR_ARG, "dm_in_conv_fwd: null argument");
-  const int M = B * H * W, ppb = 128;
-  hipLaunchKernelGGL(small_to_big_kernel, dim3(dm_cdiv(M, ppb)), dim3(NT), Cs * 9 * Cb * 4, (hipStream_t)stream, x, w, bias,
-                     (bf16_t*)y, B, Cs, H, W, Cb, 1, 1, ppb);
+  launch_small_to_big(x, w, bias, (bf16_t*)y, B, Cs, H, W, Cb, 1, 1, (hipStream_t)stream);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
@@ -417,9 +638,7 @@ extern "C" int dm_out_conv_dgrad(const float* dy, const float* w, void* dh, int 
   int rc = check_edge("dm_out_conv_dgrad", B, Cs, H, W, Cb);
   if (rc) return rc;
   DM_REQUIRE(dy && w && dh, DM_ERR_ARG, "dm_out_conv_dgrad: null argument");
-  const int M = B * H * W, ppb = 128;
-  hipLaunchKernelGGL(small_to_big_kernel, dim3(dm_cdiv(M, ppb)), dim3(NT), Cs * 9 * Cb * 4, (hipStream_t)stream, dy, w,
-                     (const float*)nullptr, (bf16_t*)dh, B, Cs, H, W, Cb, -1, 0, ppb);
+  launch_small_to_big(dy, w, nullptr, (bf16_t*)dh, B, Cs, H, W, Cb, -1, 0, (hipStream_t)stream);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
@@ -429,12 +648,26 @@ extern "C" int dm_out_conv_fwd(const void* h, const float* w, const float* bias,
   int rc = check_edge("dm_out_conv_fwd", B, Cs, H, W, Cb);
   if (rc) return rc;
   DM_REQUIRE(h && w && y, DM_ERR_ARG, "dm_out_conv_fwd: null argument");
-  const int M = B * H * W, ppb = 256;
+  const int M = B * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* hb = (const bf16_t*)h;
+  if (g_dm_edge_mfma && Cb % 32 == 0) {
+    // 128 pixels per workgroup (32 per wave): several workgroups per CU hide each other's load latency
+    const int ppb = 128, lds = 9 * (Cb / 32) * 2 * Cs * 4 * 16;   // at most 72 KiB (Cs = 4, Cb = 512)
+    const dim3 grid(dm_cdiv(M, ppb));
+    switch (Cs) {
+      case 1: hipLaunchKernelGGL(big_to_small_mfma_kernel<1>, grid, dim3(NT), lds, st, hb, w, bias, y, B, H, W, Cb, ppb); break;
+      case 2: hipLaunchKernelGGL(big_to_small_mfma_kernel<2>, grid, dim3(NT), lds, st, hb, w, bias, y, B, H, W, Cb, ppb); break;
+      case 3: hipLaunchKernelGGL(big_to_small_mfma_kernel<3>, grid, dim3(NT), lds, st, hb, w, bias, y, B, H, W, Cb, ppb); break;
+      default: hipLaunchKernelGGL(big_to_small_mfma_kernel<4>, grid, dim3(NT), lds, st, hb, w, bias, y, B, H, W, Cb, ppb); break;
+    }
+    DM_CHECK_LAUNCH();
+    return DM_OK;
+  }
+  const int ppb = 256;
   DM_REQUIRE(9 * Cs * Cb * 4 <= 65536, DM_ERR_UNSUPPORTED, "dm_out_conv_fwd: %d x %d weights exceed 64 KiB of LDS", Cs, Cb);
   const dim3 grid(dm_cdiv(M, ppb));
   const int lds = 9 * Cs * Cb * 4;
-  hipStream_t st = (hipStream_t)stream;
-  const bf16_t* hb = (const bf16_t*)h;
   switch (Cs) {
     case 1: hipLaunchKernelGGL(big_to_small_kernel<1>, grid, dim3(NT), lds, st, hb, w, bias, y, B, H, W, Cb, ppb); break;
     case 2: hipLaunchKernelGGL(big_to_small_kernel<2>, grid, dim3(NT), lds, st, hb, w, bias, y, B, H, W, Cb, ppb); break;

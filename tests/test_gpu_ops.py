@@ -429,8 +429,22 @@ def test_class_embed():
         assert max_abs(ed.grad, er.grad) == 0.0 and max_abs(td.grad, tr.grad) < 1e-6
 
 
-@pytest.mark.parametrize("B,Cs,H,W,Cb", [(2, 3, 8, 8, 64), (3, 1, 7, 7, 64), (2, 3, 16, 16, 128), (1, 3, 5, 9, 128)])
-def test_edge_convs(B, Cs, H, W, Cb):
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("B,Cs,H,W,Cb", [(2, 3, 8, 8, 64), (3, 1, 7, 7, 64), (2, 3, 16, 16, 128), (1, 3, 5, 9, 128),
+                                         (5, 4, 9, 6, 128), (2, 2, 32, 32, 32), (130, 3, 32, 32, 128)])
+def test_edge_convs(B, Cs, H, W, Cb, mfma):
+    """in_conv / out_conv forward and backward against torch fp32. mfma=1: the forward and data-gradient kernels on
+    the matrix cores (fp32 operands as hi + lo bf16 pairs), mfma=0: the VALU kernels (which also serve feature widths
+    that are not multiples of 16 / 32). The last case has a ragged last workgroup."""
+    from dm_hip import lib
+    lib.dm_config_set(b"edge_mfma", mfma)
+    try:
+        _edge_convs_case(B, Cs, H, W, Cb)
+    finally:
+        lib.dm_config_set(b"edge_mfma", 1)
+
+
+def _edge_convs_case(B, Cs, H, W, Cb):
     from dm_hip import ops
     rs = np.random.RandomState(B + Cs + H + Cb)
     d = dev()
