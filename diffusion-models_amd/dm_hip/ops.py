@@ -5,6 +5,7 @@ format, i.e. physically pixel-major [B][H][W][C] as the kernels expect; token te
 memory. Parameters stay fp32 in the reference's shapes. Every function here needs a HIP device tensor.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -163,8 +164,36 @@ def side_streams(device):
     return [s for (d, _), s in _SIDE.items() if d == device]
 
 
+# Named auxiliary streams (aux_stream): whole branches of the network that a module runs beside the main stream (the
+# embedding path). Autograd runs such a branch's backward on the same stream, where it may write parameter gradients.
+_AUX = {}         # raw stream handle -> torch stream
+# The embedding path of the UNet (time MLP, class table, every block's projection: a dozen small fp32 kernels that
+# nothing but the first block's second GroupNorm waits for) runs on an auxiliary stream beside the first convolutions,
+# and its backward beside the last ones.
+EMB_SIDE_STREAM = os.environ.get("DM_EMB_SIDE", "1") != "0"
+
+
+def aux_stream(device, name):
+    s = _SIDE.get((device, name))
+    if s is None:
+        s = _SIDE[(device, name)] = torch.cuda.Stream(device=device)
+        _AUX[s.cuda_stream] = s
+    return s
+
+
+def aux_streams():
+    return list(_AUX.values())
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of the current stream (what the kernels launch on); work on an auxiliary stream marks it as one
+    that the consumer of the gradients has to wait for."""
+    raw = torch.cuda.current_stream().cuda_stream
+    if _AUX:
+        s = _AUX.get(raw)
+        if s is not None:
+            SIDE_TOUCHED.add(s)
+    return raw
 
 
 def _p(t):

@@ -233,13 +233,27 @@ class TrainStep:
         self._sums.flush()
 
     def _join_sides(self):
-        """The weight/bias gradient kernels ran on side streams: the current stream waits for every one that was given
-        work since the last join, before anything reads the gradient arena."""
+        """The weight/bias gradient kernels ran on side streams, the embedding path's backward on an auxiliary one:
+        the current stream waits for every one that was given work since the last join, before anything reads the
+        gradient arena. While capturing, also for every auxiliary stream that autograd pulled into the capture (a
+        wait for a gradient is enough); never for a stream outside the capture. Returns the streams waited for."""
         cur = torch.cuda.current_stream()
-        for side in list(ops.SIDE_TOUCHED):
+        joined = list(ops.SIDE_TOUCHED)
+        capturing = torch.cuda.is_current_stream_capturing()
+        for aux in ops.aux_streams():
+            if aux in joined:
+                continue
+            if capturing:
+                with torch.cuda.stream(aux):
+                    inside = torch.cuda.is_current_stream_capturing()
+                if not inside:
+                    continue
+            joined.append(aux)
+        for side in joined:
             cur.wait_stream(side)
         ops.SIDE_TOUCHED.clear()
         ops.SIDE_KEEP.clear()
+        return joined
 
     # ---- forward + backward captured as a chain of HIP graphs cut at bucket boundaries ---------------------------
     def _cut(self, b):
@@ -247,13 +261,21 @@ class TrainStep:
         current graph behind everything that produced the bucket and open the next one. At replay the bucket's
         all-reduce is issued between the two graphs and runs beside the rest of backward."""
         seg = self._seg
-        self._join_sides()
-        self._sums.flush()
-        seg["graphs"][-1].capture_end()
-        seg["after"].append([b])
-        g = torch.cuda.CUDAGraph()
-        g.capture_begin(pool=seg["pool"], capture_error_mode="relaxed")
-        seg["graphs"].append(g)
+        # on the capture's own stream: the report may come from an operator running on an auxiliary stream
+        with torch.cuda.stream(seg["stream"]):
+            joined = self._join_sides()
+            self._sums.flush()
+            seg["graphs"][-1].capture_end()
+            seg["after"].append([b])
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=seg["pool"], capture_error_mode="relaxed")
+            seg["graphs"].append(g)
+            # auxiliary streams go on into the new capture: operators queued on them later (autograd keeps a branch
+            # on its stream without any new wait) must land in a graph, not run eagerly during capture
+            for aux in ops.aux_streams():
+                if aux in joined:
+                    aux.wait_stream(seg["stream"])
+                    ops.SIDE_TOUCHED.add(aux)
 
     def capture_segmented(self, x=None, label=None, stream=None, loss_fn=None):
         """Capture forward + backward of one step (train.py:429-440) on (x, label) as a chain of HIP graphs, cut at
@@ -268,7 +290,7 @@ class TrainStep:
         stream = stream or torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.synchronize()
-        seg = self._seg = {"graphs": [], "after": [], "pool": torch.cuda.graph_pool_handle()}
+        seg = self._seg = {"graphs": [], "after": [], "pool": torch.cuda.graph_pool_handle(), "stream": stream}
         with torch.cuda.stream(stream):
             # (relaxed mode: autograd runs backward on its own thread, so a capture begun on this one is ended
             # on that one at the first cut, and the last one the other way round)

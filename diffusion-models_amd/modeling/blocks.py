@@ -23,7 +23,8 @@ class ProjectedEmbeddings:
     MAX_GROUP = 32
 
     def __init__(self, embedding: torch.Tensor, blocks):
-        self.raw = embedding
+        self._raw = embedding
+        self._side = None
         blocks = [b for b in blocks if b.emb_proj is not None and is_silu(b.nonlinearity)]
         self._proj = {}
         for i in range(0, len(blocks), self.MAX_GROUP):
@@ -31,7 +32,25 @@ class ProjectedEmbeddings:
             outs = ops.linear_group(embedding, [(b.emb_proj.weight, b.emb_proj.bias) for b in chunk], act_in=True)
             self._proj.update({id(b): o for b, o in zip(chunk, outs)})
 
+    def produced_on(self, stream):
+        """The tensors were computed on `stream` (not the consumers' stream): the first consumer waits for it."""
+        self._side = stream
+
+    def join(self):
+        if self._side is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._side)
+            for t in [self._raw] + list(self._proj.values()):
+                t.record_stream(cur)     # allocated on the other stream's pool, used on this one
+            self._side = None
+
+    @property
+    def raw(self):
+        self.join()
+        return self._raw
+
     def for_block(self, block):
+        self.join()
         return self._proj.get(id(block))
 
 

@@ -97,14 +97,18 @@ class UNet(nn.Module, GuidedPredictor):
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, cls: Optional[torch.Tensor] = None,
                 uncond_mask: Optional[torch.Tensor] = None):
-        embedding = self.time_embedding(t)
-        if self.class_embedding is not None:
-            # masked / missing labels map to the padding row, which is zero and never receives gradient
-            embedding = ops.class_embed_add(embedding, self.class_embedding.weight, cls,
-                                            uncond_mask if cls is not None else None, self._uncond_idx)
-
-        # every ConvBlock projects the same SiLU(embedding): do all projections in one grouped launch
-        embedding = ProjectedEmbeddings(embedding, self._conv_blocks)
+        if x.is_cuda and ops.EMB_SIDE_STREAM:
+            # the embedding path beside the first convolutions: its first consumer is the first block's second norm
+            side, cur = ops.aux_stream(x.device, "embedding"), torch.cuda.current_stream()
+            side.wait_stream(cur)
+            for v in (t, cls, uncond_mask):
+                if v is not None and v.is_cuda:
+                    v.record_stream(side)
+            with torch.cuda.stream(side):
+                embedding = self._embed(t, cls, uncond_mask)
+            embedding.produced_on(side)
+        else:
+            embedding = self._embed(t, cls, uncond_mask)
 
         h = self.in_conv(x)
         skips = (h,)
@@ -119,11 +123,21 @@ class UNet(nn.Module, GuidedPredictor):
             stage_skips, skips = skips[-n:], skips[:-n]
             h = stage(h, stage_skips, embedding=embedding)
 
+        embedding.join()   # (a network without embedding consumers still leaves no stream unjoined)
         if is_silu(self.out_act):
             h = self.out_norm(h, act=True)
         else:
             h = self.out_act(self.out_norm(h, act=False))
         return self.out_conv(h)
+
+    def _embed(self, t, cls, uncond_mask):
+        embedding = self.time_embedding(t)
+        if self.class_embedding is not None:
+            # masked / missing labels map to the padding row, which is zero and never receives gradient
+            embedding = ops.class_embed_add(embedding, self.class_embedding.weight, cls,
+                                            uncond_mask if cls is not None else None, self._uncond_idx)
+        # every ConvBlock projects the same SiLU(embedding): do all projections in one grouped launch
+        return ProjectedEmbeddings(embedding, self._conv_blocks)
 
     def pred_conditional(self, z, t, cond=None, uncond_mask=None):
         return self.forward(z, t, cls=cond, uncond_mask=uncond_mask)
