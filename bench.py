@@ -218,13 +218,13 @@ def cpu_baseline(cfg, budget_s=20.0, batch=16):
 
 
 def sampling_row(model, cfg, device, rank, world, config_name, sampler_type=None, n_steps=None, batch=256,
-                 repeats=1, warmup=1, use_graph=True):
+                 repeats=1, warmup=1, use_graph=True, chains=1):
     """Sampling throughput of one (sampler, n_steps) setting: every rank runs the whole n-step loop on `batch` images
     (train.py:476-504: get_pred_fn + sampler.sample + clip), UNet forward replayed from a HIP graph. Returns a dict
     (on every rank; times are the max over ranks)."""
     from diffusion.sampler import get_sampler
     from diffusion.scheduler import get_scheduler
-    from harness.generate import GraphedPredictor
+    from harness.generate import GraphedPredictor, interleaved_pred_fn
     sched = get_scheduler(cfg["scheduler_type"], **cfg["scheduler_cfg"])
     stype = sampler_type or cfg["sampler_type"]
     scfg = dict(cfg["sampler_cfg"]) if stype == cfg["sampler_type"] else {}
@@ -238,7 +238,7 @@ def sampling_row(model, cfg, device, rank, world, config_name, sampler_type=None
     cls = torch.randint(0, 10, (batch,), generator=g).to(device)
     was_training = model.training
     model.eval()
-    pred = model.get_pred_fn(cond=cls, guidance_scale=cfg.get("guidance_scale", 1.0))
+    pred = interleaved_pred_fn(model, cls, cfg.get("guidance_scale", 1.0), chains)
     if use_graph:
         pred = GraphedPredictor(pred)
 
@@ -278,6 +278,7 @@ def sampling_row(model, cfg, device, rank, world, config_name, sampler_type=None
             "s_per_batch": round(per, 4), "unet_forward_ms": round(per * 1e3 / n, 3),
             "tflops": round(tf, 1) if tf else None,
             "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4) if tf else None, "hip_graph": bool(use_graph),
+            "interleaved_sub_batches": chains,
             "activations": "bf16 (the reference samples in fp32)"}
 
 
@@ -288,7 +289,7 @@ def bench_sampling(args, cfg, device, rank, world):
     model = get_model(cfg["model_type"], **cfg["model_cfg"]).to(device).eval()
     row = sampling_row(model, cfg, device, rank, world, args.config, sampler_type=args.sampler,
                        n_steps=args.sample_steps, batch=args.sample_batch, repeats=args.steps, warmup=args.warmup,
-                       use_graph=not args.no_graph)
+                       use_graph=not args.no_graph, chains=args.sample_chains)
     if rank == 0:
         emit({
             "metric": f"sample imgs/sec @{row['n_steps']} steps ({row['sampler']})", "value": row["img_s"],
@@ -342,6 +343,8 @@ def main():
                     help="train: the training step (the headline metric); sample: the sampling loop of the config")
     ap.add_argument("--sample-batch", type=int, default=256, help="images per GPU per sampling batch (generation_batch_size)")
     ap.add_argument("--sample-steps", type=int, default=None, help="sampler steps (default: the config's)")
+    ap.add_argument("--sample-chains", type=int, default=2,
+                    help="run every UNet forward of the sampling loop as this many interleaved sub-batches on streams of their own")
     ap.add_argument("--sampler", default=None, help="sampler type override for --mode sample (ddpm, ddim, euler)")
     ap.add_argument("--no-sampling", action="store_true",
                     help="train mode: skip the sampling rows (config sampler, and DDPM ancestral 1000 steps on VP configs)")
@@ -503,10 +506,11 @@ def main():
     # sampling over all 1000 steps where the scheduler is variance preserving
     sampling = None
     if not args.no_sampling:
-        sampling = [sampling_row(model, cfg, device, rank, world, args.config, batch=args.sample_batch)]
+        sampling = [sampling_row(model, cfg, device, rank, world, args.config, batch=args.sample_batch, chains=args.sample_chains)]
         if sched.pred_type == "noise":
             sampling.append(sampling_row(model, cfg, device, rank, world, args.config, sampler_type="ddpm",
-                                         n_steps=cfg["scheduler_cfg"]["n_steps"], batch=args.sample_batch, warmup=0))
+                                         n_steps=cfg["scheduler_cfg"]["n_steps"], batch=args.sample_batch, warmup=0,
+                                         chains=args.sample_chains))
 
     if rank == 0:
         step_tflop = 3 * FWD_GFLOP_PER_IMG.get(args.config, 0.0) * batch / 1e3

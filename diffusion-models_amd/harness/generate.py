@@ -123,6 +123,49 @@ class GraphedPredictor:
         return self.out
 
 
+def interleaved_pred_fn(model, cond: Optional[torch.Tensor], guidance_scale: float, chains: int):
+    """pred_fn(z, t) that runs the batch as `chains` independent sub-batches, each on a stream of its own. The rows of
+    a batch do not interact anywhere in the network (GroupNorm is per sample), so the result is the same bit for bit;
+    what changes is the schedule: a forward pass is a strict chain of MFMA-bound convolutions and HBM-bound GroupNorm
+    kernels, and two chains half a layer out of phase keep both the matrix cores and the memory system busy.
+    Works eagerly and under HIP-graph capture (the forks and joins are captured)."""
+    if chains <= 1:
+        return model.get_pred_fn(cond=cond, guidance_scale=guidance_scale)
+    device = next(model.parameters()).device
+    streams = [torch.cuda.Stream(device=device) for _ in range(chains)]
+    fns = {}
+
+    def pred(z, t):
+        B = z.shape[0]
+        bounds = [shard_bounds(B, chains, c) for c in range(chains)]
+        if B not in fns:   # per sub-batch closures over views of the (persistent) label buffer
+            fns[B] = [model.get_pred_fn(cond=None if cond is None else cond[lo:hi], guidance_scale=guidance_scale)
+                      for lo, hi in bounds]
+        from dm_hip import ops
+        cur = torch.cuda.current_stream()
+        out = torch.empty_like(z, dtype=torch.float32)
+        # the network's own side stream for the embedding path stays off inside the chains: a fork inside a forked
+        # stream, twice in one capture, crashes the HIP runtime's graph capture (ROCm 7.2), and the other chain already
+        # fills the gaps it would fill
+        emb_side, ops.EMB_SIDE_STREAM = ops.EMB_SIDE_STREAM, False
+        try:
+            for s, (lo, hi), f in zip(streams, bounds, fns[B]):
+                if hi == lo:
+                    continue
+                s.wait_stream(cur)
+                for v in (z, t, out):
+                    v.record_stream(s)
+                with torch.cuda.stream(s):
+                    out[lo:hi].copy_(f(z[lo:hi], t[lo:hi]))
+        finally:
+            ops.EMB_SIDE_STREAM = emb_side
+        for s in streams:
+            cur.wait_stream(s)
+        return out
+
+    return pred
+
+
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous shard [lo, hi) of n items for `rank`; the first n % world ranks hold one more item."""
     base, extra = divmod(n, world)
@@ -133,13 +176,16 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
 @torch.no_grad()
 def generate(model, sampler, scheduler, z: torch.Tensor, cls: Optional[torch.Tensor] = None,
              guidance_scale: float = 1.0, batch_size: int = 256, use_graph: bool = True,
-             process_group=None, gather: bool = True, sampler_kwargs: Optional[Dict] = None) -> torch.Tensor:
+             process_group=None, gather: bool = True, sampler_kwargs: Optional[Dict] = None,
+             chains: int = 2) -> torch.Tensor:
     """Generate one image per row of z (train.py:476-504), sharded over the ranks of `process_group`.
 
     z / cls are the full seed tensors (host or device), identical on every rank. Returns the clipped fp32
     samples on the host: all of them on every rank when `gather`, else this rank's shard.
     Every batch starts its own `sampler.sample()` call, so a DDPM sampler re-creates its default-seeded noise
     generator per batch exactly as the reference does.
+    chains: run every UNet forward as this many interleaved sub-batches (interleaved_pred_fn); same images, about
+    15 % more of them per second at batch 256 with 2 (measured: UNet forward 5.9 -> 5.1 ms).
     """
     device = next(model.parameters()).device
     world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -162,10 +208,10 @@ def generate(model, sampler, scheduler, z: torch.Tensor, cls: Optional[torch.Ten
         if use_graph:
             key = (b1 - b0, cond is not None)
             if key not in graphed:
-                graphed[key] = GraphedPredictor(model.get_pred_fn(cond=cond, guidance_scale=guidance_scale))
+                graphed[key] = GraphedPredictor(interleaved_pred_fn(model, cond, guidance_scale, chains))
             pred_fn = graphed[key]
         else:
-            pred_fn = model.get_pred_fn(cond=cond, guidance_scale=guidance_scale)
+            pred_fn = interleaved_pred_fn(model, cond, guidance_scale, chains)
         samples = sampler.sample(zb, scheduler, pred_fn, **sampler_kwargs)
         outs.append(torch.clip(samples, -1, 1).cpu())
     if was_training:

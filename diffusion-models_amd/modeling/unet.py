@@ -99,7 +99,10 @@ class UNet(nn.Module, GuidedPredictor):
                 uncond_mask: Optional[torch.Tensor] = None):
         if x.is_cuda and ops.EMB_SIDE_STREAM:
             # the embedding path beside the first convolutions: its first consumer is the first block's second norm
-            side, cur = ops.aux_stream(x.device, "embedding"), torch.cuda.current_stream()
+            # (one auxiliary stream per calling stream: callers that run several sub-batches on streams of their own
+            # must not meet on a shared one)
+            cur = torch.cuda.current_stream()
+            side = ops.aux_stream(x.device, ("embedding", cur.cuda_stream))
             side.wait_stream(cur)
             for v in (t, cls, uncond_mask):
                 if v is not None and v.is_cuda:

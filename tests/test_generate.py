@@ -88,8 +88,13 @@ def test_generate_graph_replay_equals_eager(sampler_name, kwargs):
     hw = 16
     z = torch.randn(5, TINY_CFG["in_channels"], hw, hw, generator=g)
     cls = torch.randint(0, 10, (5,), generator=g) if TINY_CFG.get("n_class_embeddings") else None
-    eager = generate(model, sampler, sched, z, cls, batch_size=2, use_graph=False)
-    graphed = generate(model, sampler, sched, z, cls, batch_size=2, use_graph=True)
+    eager = generate(model, sampler, sched, z, cls, batch_size=2, use_graph=False, chains=1)
+    graphed = generate(model, sampler, sched, z, cls, batch_size=2, use_graph=True, chains=1)
     assert eager.shape == z.shape and eager.dtype == torch.float32
     assert float(eager.abs().max()) <= 1.0
     assert torch.equal(eager, graphed)
+    # every UNet forward as interleaved sub-batches on streams of their own (2: the default; 3: ragged sub-batches,
+    # one of them empty on the last batch of one image): the same images, eagerly and replayed
+    for chains, use_graph in ((2, True), (2, False), (3, True)):
+        again = generate(model, sampler, sched, z, cls, batch_size=2, use_graph=use_graph, chains=chains)
+        assert torch.equal(eager, again), (chains, use_graph)
