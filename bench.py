@@ -130,6 +130,9 @@ class AbiTimer:
                 shape = (m, d.Cout, d.C1 + d.C2, d.KH, d.stride, d.ups, d.transposed)
             else:
                 work, nbytes, shape = 0.0, float(HBM_OPS[name][1](args)), None
+                if name.startswith("dm_groupnorm_act"):
+                    g = args[0]._obj
+                    shape = ("gn", name[17:], g.B, g.HW, g.C1, g.C2, bool(len(args) > 10 and name.endswith("bwd") and args[10]))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = fn(*args)
@@ -148,7 +151,10 @@ class AbiTimer:
         dump = os.environ.get("DM_BENCH_DUMP_CONVS")
         for name, flops, e0, e1, nbytes, shape in self.records:
             ms = e0.elapsed_time(e1)
-            if dump and shape:
+            if dump and shape and shape[0] == "gn":
+                sys.stderr.write(f"[gn] {shape[1]} B={shape[2]} HW={shape[3]:5d} C={shape[4]}+{shape[5]} extra={int(shape[6])} "
+                                 f"{nbytes / 1e6:7.1f} MB {ms * 1e3:7.1f} us {nbytes / ms / 1e9:6.2f} TB/s\n")
+            elif dump and shape:
                 sys.stderr.write(f"[conv] {name[11:]:6s} M={shape[0]:6d} N={shape[1]:4d} C={shape[2]:4d} k={shape[3]} s={shape[4]} "
                                  f"ups={shape[5]} T={shape[6]} {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF\n")
             s = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
