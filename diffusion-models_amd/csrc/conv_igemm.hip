@@ -238,11 +238,45 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(ConvArgs a) {
 }  // namespace
 
 int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
-                      const void* res, void* y, hipStream_t st);
+                      const void* res, void* y, hipStream_t st, const dm_gn_desc* g, const float* gamma,
+                      const float* beta, const float* ss, const float* pre, void* y_norm, float* mean,
+                      float* rstd);
+int dm_conv_patch_gn_ok(const dm_conv_desc* d, const dm_gn_desc* g);
 extern int g_dm_use_patch_kernel;
+extern int g_dm_conv_gn_fuse;
+
+static int conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                        const void* res, void* y, void* stream, const dm_gn_desc* g, const float* gamma,
+                        const float* beta, const float* ss, const float* pre, void* y_norm, float* mean,
+                        float* rstd);
 
 extern "C" int dm_conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const void* w,
                                const float* bias, const void* res, void* y, void* stream) {
+  return conv2d_igemm(d, x1, x2, w, bias, res, y, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      nullptr);
+}
+
+extern "C" int dm_conv2d_gn_fusable(const dm_conv_desc* d, const dm_gn_desc* g) {
+  return d && g && g_dm_use_patch_kernel && g_dm_conv_gn_fuse && !d->transposed && dm_conv_patch_gn_ok(d, g);
+}
+
+extern "C" int dm_conv2d_igemm_gn(const dm_conv_desc* d, const void* x1, const void* x2, const void* w,
+                                  const float* bias, const void* res, void* y, const dm_gn_desc* g, const float* gamma,
+                                  const float* beta, const float* scale_shift, const float* pre_add, void* y_norm,
+                                  float* mean, float* rstd, void* stream) {
+  DM_REQUIRE(g && gamma && beta && y_norm && mean && rstd, DM_ERR_ARG, "dm_conv2d_igemm_gn: null argument");
+  DM_REQUIRE((g->has_ss != 0) == (scale_shift != nullptr) && (g->has_pre != 0) == (pre_add != nullptr), DM_ERR_ARG,
+             "dm_conv2d_igemm_gn: scale_shift/pre_add pointers disagree with the descriptor");
+  DM_REQUIRE(dm_conv2d_gn_fusable(d, g), DM_ERR_UNSUPPORTED,
+             "dm_conv2d_igemm_gn: this layer's tiles do not hold whole samples and groups (ask dm_conv2d_gn_fusable first)");
+  DM_REQUIRE((uintptr_t)y_norm % 16 == 0, DM_ERR_ARG, "dm_conv2d_igemm_gn: pointers must be 16-byte aligned");
+  return conv2d_igemm(d, x1, x2, w, bias, res, y, stream, g, gamma, beta, scale_shift, pre_add, y_norm, mean, rstd);
+}
+
+static int conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                        const void* res, void* y, void* stream, const dm_gn_desc* g, const float* gamma,
+                        const float* beta, const float* ss, const float* pre, void* y_norm, float* mean,
+                        float* rstd) {
   DM_REQUIRE(d && x1 && w && y, DM_ERR_ARG, "dm_conv2d_igemm: null argument");
   DM_REQUIRE(d->C1 > 0 && d->C1 % BK == 0 && d->C2 >= 0 && d->C2 % BK == 0, DM_ERR_SHAPE,
              "dm_conv2d_igemm: input channels (%d, %d) must be multiples of %d", d->C1, d->C2, BK);
@@ -271,10 +305,13 @@ extern "C" int dm_conv2d_igemm(const dm_conv_desc* d, const void* x1, const void
   DM_REQUIRE(((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)res | (uintptr_t)y) % 16 == 0,
              DM_ERR_ARG, "dm_conv2d_igemm: pointers must be 16-byte aligned");
   // 3x3 stride-1 convs (and their data gradients) go to the LDS-staged-patch kernel when the shape allows
-  if (g_dm_use_patch_kernel && dm_conv_patch_try(d, x1, x2, w, bias, res, y, (hipStream_t)stream) == DM_OK) {
+  if (g_dm_use_patch_kernel &&
+      dm_conv_patch_try(d, x1, x2, w, bias, res, y, (hipStream_t)stream, g, gamma, beta, ss, pre, y_norm, mean,
+                        rstd) == DM_OK) {
     DM_CHECK_LAUNCH();
     return DM_OK;
   }
+  DM_REQUIRE(!g, DM_ERR_UNSUPPORTED, "dm_conv2d_igemm_gn: layer not covered by the patch kernel");
 
   ConvArgs a;
   a.x1 = x1; a.x2 = x2; a.w = w; a.bias = bias; a.res = res; a.y = y;

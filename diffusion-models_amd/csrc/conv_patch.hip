@@ -39,6 +39,17 @@ struct PatchArgs {
   int TR, PW;  // rows per tile, patch width (W + 2)
   int M, n_mtiles, n_ntiles;
   unsigned x1_bytes, x2_bytes, w_bytes;
+  // optional GroupNorm(+scale/shift)(+SiLU) of the output in the epilogue (gn_y != null): the tile must hold whole
+  // samples (BM % gn_hw == 0) and whole groups (BN % gn_cg == 0)
+  const float* gn_gamma;
+  const float* gn_beta;
+  const float* gn_ss;     // [B][2 Cout] or null
+  const float* gn_pre;    // [B][Cout] added to the output before the statistics, or null (not both)
+  void* gn_y;
+  float* gn_mean;
+  float* gn_rstd;
+  int gn_hw, gn_G, gn_cg, gn_act;
+  float gn_eps;
 };
 
 template <int BN, int NP>
@@ -50,7 +61,8 @@ struct Lay {
   static constexpr int STAGE_TOTAL = 2 * A_BYTES + 3 * B_BYTES;
   static constexpr int EP_PITCH = BN + 4;
   static constexpr int EP_BYTES = BM * EP_PITCH * 4;
-  static constexpr int TOTAL = STAGE_TOTAL > EP_BYTES ? STAGE_TOTAL : EP_BYTES;
+  static constexpr int GN_BYTES = 20 * 1024;   // fused GroupNorm: per-wave channel sums, then ka | kb per (sample, channel)
+  static constexpr int TOTAL = STAGE_TOTAL > EP_BYTES + GN_BYTES ? STAGE_TOTAL : EP_BYTES + GN_BYTES;
   static constexpr int B_PIECES = BN * 8 / NTHREADS;  // 16-byte pieces of a weight stage per thread
 };
 
@@ -314,27 +326,153 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
   const bf16_t* res = (const bf16_t*)a.res;
   const int m0 = R0 * a.W;              // the tile's output pixels are contiguous in memory
   const int rows_valid = min(a.TR * a.W, a.M - m0);
-#pragma unroll 2
-  for (int it = 0; it < (BM * CPR) / NTHREADS; ++it) {
-    const int item = tid + NTHREADS * it;
-    const int row = item / CPR, cch = item - row * CPR;
+  // 8 channels of one output row: accumulator + bias + residual, rounded to bf16
+  auto finish_row = [&](int row, int cch) -> bf16x8_t {
+    const float* src = ep + row * L::EP_PITCH + cch * 8;
     const int n = n0 + cch * 8;
-    if (row < rows_valid && n < a.Cout) {
-      const float* src = ep + row * L::EP_PITCH + cch * 8;
-      const f32x4_t v0 = *(const f32x4_t*)src, v1 = *(const f32x4_t*)(src + 4);
-      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (a.bias) {
-        const f32x4_t c0 = *(const f32x4_t*)(a.bias + n), c1 = *(const f32x4_t*)(a.bias + n + 4);
+    const f32x4_t v0 = *(const f32x4_t*)src, v1 = *(const f32x4_t*)(src + 4);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    if (a.bias) {
+      const f32x4_t c0 = *(const f32x4_t*)(a.bias + n), c1 = *(const f32x4_t*)(a.bias + n + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] += c0[j]; v[4 + j] += c1[j]; }
-      }
-      const size_t o = (size_t)(m0 + row) * a.Cout + n;
-      if (res) {
-        const bf16x8_t rv = *(const bf16x8_t*)(res + o);
+      for (int j = 0; j < 4; ++j) { v[j] += c0[j]; v[4 + j] += c1[j]; }
+    }
+    if (res && row < rows_valid) {
+      const bf16x8_t rv = *(const bf16x8_t*)(res + (size_t)(m0 + row) * a.Cout + n);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+      for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+    }
+    return dm_pack8(v);
+  };
+  if (a.gn_y == nullptr) {
+#pragma unroll 2
+    for (int it = 0; it < (BM * CPR) / NTHREADS; ++it) {
+      const int item = tid + NTHREADS * it;
+      const int row = item / CPR, cch = item - row * CPR;
+      if (row < rows_valid && n0 + cch * 8 < a.Cout)
+        *(bf16x8_t*)(y + (size_t)(m0 + row) * a.Cout + n0 + cch * 8) = finish_row(row, cch);
+    }
+    return;
+  }
+
+  // ---- with the GroupNorm (+ per-sample scale/shift or pre-add) (+ SiLU) of the output. The tile holds S = BM / HW
+  // whole samples and BN / cg whole groups (the host has checked); every thread keeps its share of the rounded output
+  // in registers: y2 = act(ka * y + kb), ka = (1 + scale) gamma rstd, kb = ka (pre - mean) + (1 + scale) beta + shift.
+  // All sums run in a fixed order that does not depend on where in a tile (or a batch) a sample sits.
+  // Order of the sums over a sample's rows, the same for both tile widths: rows fall into 64 classes (row mod 64), a
+  // class adds its rows in ascending order, classes 8w .. 8w+7 (held by wave w) add up as a butterfly over the class
+  // bits, the eight waves' sums in ascending order. (64-wide tiles: a thread has one class; 128-wide: two, 2 rg and
+  // 2 rg + 1, on alternating iterations.)
+  constexpr int RPI = NTHREADS / CPR;   // rows per iteration of the whole workgroup
+  constexpr int CLS = 64 / RPI;         // classes per thread
+  constexpr int NIT = BM / RPI;
+  constexpr int NW = NTHREADS / 64;
+  const int HW = a.gn_hw, S = BM / HW, ips = HW / RPI;   // iterations per sample (HW is a multiple of 64)
+  float* part = (float*)(smem + L::EP_BYTES);            // [S][NW][2][BN] per-wave channel sums
+  float* kab = part + S * NW * 2 * BN;                   // [S][2][BN] ka | kb
+  const int cch = tid % CPR, rg = tid / CPR;
+  auto row_of = [&](int it) { return CLS * rg + it % CLS + 64 * (it / CLS); };
+  bf16x8_t keep[NIT];
+  float s1[CLS][8], s2[CLS][8];
+#pragma unroll
+  for (int k = 0; k < CLS; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[k][j] = s2[k][j] = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = row_of(it);
+    keep[it] = finish_row(row, cch);
+    if (row < rows_valid) *(bf16x8_t*)(y + (size_t)(m0 + row) * a.Cout + n0 + cch * 8) = keep[it];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // statistics of what a separate kernel would read back: the rounded values
+      const float f = (float)keep[it][j];
+      s1[it % CLS][j] += f;
+      s2[it % CLS][j] += f * f;
+    }
+    if ((it + 1) % ips == 0) {      // the sample's last rows: lanes that share the channels add up, one of them files
+      const int sidx = it / ips;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t1 = s1[0][j], t2 = s2[0][j];
+        if (CLS == 2) { t1 += s1[CLS - 1][j]; t2 += s2[CLS - 1][j]; }
+#pragma unroll
+        for (int m = CPR; m < 64; m <<= 1) {
+          t1 += __shfl_xor(t1, m);
+          t2 += __shfl_xor(t2, m);
+        }
+        s1[0][j] = t1;
+        s2[0][j] = t2;
       }
-      *(bf16x8_t*)(y + o) = dm_pack8(v);
+      if (lane < CPR) {
+        float* dst = part + ((sidx * NW + wave) * 2) * BN + cch * 8;
+        *(f32x4_t*)dst = f32x4_t{s1[0][0], s1[0][1], s1[0][2], s1[0][3]};
+        *(f32x4_t*)(dst + 4) = f32x4_t{s1[0][4], s1[0][5], s1[0][6], s1[0][7]};
+        *(f32x4_t*)(dst + BN) = f32x4_t{s2[0][0], s2[0][1], s2[0][2], s2[0][3]};
+        *(f32x4_t*)(dst + BN + 4) = f32x4_t{s2[0][4], s2[0][5], s2[0][6], s2[0][7]};
+      }
+#pragma unroll
+      for (int k = 0; k < CLS; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1[k][j] = s2[k][j] = 0.f;
+    }
+  }
+  __syncthreads();
+  const int b_first = m0 / HW;
+  if (tid < S * BN) {   // one thread per (sample, channel); a group's cg channels sit in adjacent lanes of one wave
+    const int sidx = tid / BN, c = tid - sidx * BN, cj = n0 + c, b = b_first + sidx;
+    const bool live = sidx * HW < rows_valid;
+    float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      u1 += part[((sidx * NW + w) * 2) * BN + c];
+      u2 += part[((sidx * NW + w) * 2 + 1) * BN + c];
+    }
+    const float pv = (a.gn_pre && live) ? a.gn_pre[(size_t)b * a.Cout + cj] : 0.f;
+    u2 += 2.f * pv * u1 + (float)HW * pv * pv;   // statistics of y + pre from those of y
+    u1 += (float)HW * pv;
+    for (int m = 1; m < a.gn_cg; m <<= 1) {      // (every lane of a group ends with the same bits: a + b == b + a)
+      u1 += __shfl_xor(u1, m);
+      u2 += __shfl_xor(u2, m);
+    }
+    const float inv_n = 1.0f / (float)(a.gn_cg * HW);
+    const float mu = u1 * inv_n;
+    const float var = fmaxf(u2 * inv_n - mu * mu, 0.f);
+    const float r = rsqrtf(var + a.gn_eps);
+    float ka = 0.f, kb = 0.f;
+    if (live) {
+      float sc = 1.f, sh = 0.f;
+      if (a.gn_ss) { sc = 1.f + a.gn_ss[(size_t)b * 2 * a.Cout + cj]; sh = a.gn_ss[(size_t)b * 2 * a.Cout + a.Cout + cj]; }
+      ka = sc * a.gn_gamma[cj] * r;
+      kb = ka * (pv - mu) + sc * a.gn_beta[cj] + sh;
+      if (c % a.gn_cg == 0) {
+        a.gn_mean[(size_t)b * a.gn_G + cj / a.gn_cg] = mu;
+        a.gn_rstd[(size_t)b * a.gn_G + cj / a.gn_cg] = r;
+      }
+    }
+    kab[(sidx * 2) * BN + c] = ka;
+    kab[(sidx * 2 + 1) * BN + c] = kb;
+  }
+  __syncthreads();
+  bf16_t* y2 = (bf16_t*)a.gn_y;
+  float ka[8], kb[8];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = row_of(it);
+    if (it % ips == 0) {
+      const float* k = kab + ((it / ips) * 2) * BN + cch * 8;
+      const f32x4_t a0 = *(const f32x4_t*)k, a1 = *(const f32x4_t*)(k + 4);
+      const f32x4_t b0_ = *(const f32x4_t*)(k + BN), b1_ = *(const f32x4_t*)(k + BN + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ka[j] = a0[j]; ka[4 + j] = a1[j]; kb[j] = b0_[j]; kb[4 + j] = b1_[j]; }
+    }
+    if (row < rows_valid) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float u = ka[j] * (float)keep[it][j] + kb[j];
+        f[j] = a.gn_act ? dm_silu(u) : u;
+      }
+      *(bf16x8_t*)(y2 + (size_t)(m0 + row) * a.Cout + n0 + cch * 8) = dm_pack8(f);
     }
   }
 }
@@ -357,22 +495,75 @@ int pick_rows(int H, int W, int cap) {
 
 // Returns DM_OK if handled, DM_ERR_UNSUPPORTED (without setting an error) when the shape is not covered and the
 // caller should use the gathered implicit-GEMM kernel.
-int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
-                      const void* res, void* y, hipStream_t st) {
-  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return DM_ERR_UNSUPPORTED;
+// Tile plan of a layer: (64-wide tiles?, rows per tile); rows = 0: the layer does not take this kernel.
+static void patch_plan(const dm_conv_desc* d, bool& bn64, int& TR, bool force64 = false) {
+  TR = 0;
+  bn64 = false;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return;
   const int H = d->Ho, W = d->Wo;
-  if (W > BM || d->Cout % 8) return DM_ERR_UNSUPPORTED;
-  if ((long)d->B * H >= (1 << 20) - BM) return DM_ERR_UNSUPPORTED;   // the kernel's float-multiply divisions are exact below 2^20
+  if (W > BM || d->Cout % 8) return;
+  if ((long)d->B * H >= (1 << 20) - BM) return;   // the kernel's float-multiply divisions are exact below 2^20
   const int Cin = d->C1 + d->C2;
-  if (Cin % BK || d->C1 % BK) return DM_ERR_UNSUPPORTED;
+  if (Cin % BK || d->C1 % BK) return;
   // narrow outputs on small images: 64-column tiles keep every CU busy
-  const long M = (long)d->B * H * W;
   // (measured with cold caches: with at most 32 row tiles, 64-column tiles win up to 1024 output channels)
+  const long M = (long)d->B * H * W;
   const long mt = M / BM, blocks128 = mt * dm_cdiv(d->Cout, 128);
-  const bool bn64 = d->Cout <= 64 || blocks128 < 200 || (mt <= 32 && blocks128 <= 256);
+  bn64 = force64 || d->Cout <= 64 || blocks128 < 200 || (mt <= 32 && blocks128 <= 256);
   const int cap = bn64 ? Lay<64, 7>::PIX_CAP : Lay<128, 6>::PIX_CAP;
-  const int TR = pick_rows(H, W, cap);
-  if (TR <= 0 || TR * W < BM / 2) return DM_ERR_UNSUPPORTED;   // too ragged to be worth it
+  const int tr = pick_rows(H, W, cap);
+  if (tr <= 0 || tr * W < BM / 2) return;         // too ragged to be worth it
+  TR = tr;
+}
+
+// Does a tile plan let the GroupNorm that follows the convolution run in its epilogue? The tile must be exactly BM
+// pixels of whole samples and BN channels of whole groups, and the workgroup must sit inside one sample at a time.
+static bool gn_plan_ok(const dm_conv_desc* d, const dm_gn_desc* g, bool bn64, int TR) {
+  if (!TR) return false;
+  const int HW = d->Ho * d->Wo, BN = bn64 ? 64 : 128;
+  if (g->C1 != d->Cout || g->C2 != 0 || g->HW != HW || g->B != d->B || (g->has_pre && g->has_ss) || g->G <= 0 ||
+      d->Cout % g->G)
+    return false;
+  const int cg = d->Cout / g->G;
+  if (TR * d->Wo != BM || BM % HW || d->Cout % BN || BN % cg) return false;
+  if (cg > 64 || (cg & (cg - 1))) return false;   // a group's channels add up across 2^k adjacent lanes
+  const int S = BM / HW;
+  if (HW % 64 || S * BN > NTHREADS) return false;
+  const int gn_bytes = (S * (NTHREADS / 64) * 2 * BN + S * 2 * BN) * 4;
+  return gn_bytes <= (bn64 ? Lay<64, 7>::GN_BYTES : Lay<128, 6>::GN_BYTES);
+}
+
+// The plan for convolution + GroupNorm: the layer's own plan if it qualifies, else 64-wide tiles if those do (whatever
+// qualifies with 128-wide tiles also does with 64-wide ones, so whether a layer qualifies does not depend on the
+// batch size, and the statistics come out of the same order of sums either way).
+static bool gn_plan(const dm_conv_desc* d, const dm_gn_desc* g, bool& bn64, int& TR) {
+  patch_plan(d, bn64, TR);
+  if (gn_plan_ok(d, g, bn64, TR)) return true;
+  if (bn64) return false;
+  patch_plan(d, bn64, TR, true);
+  return gn_plan_ok(d, g, bn64, TR);
+}
+
+int dm_conv_patch_gn_ok(const dm_conv_desc* d, const dm_gn_desc* g) {
+  bool bn64;
+  int TR;
+  return g && gn_plan(d, g, bn64, TR);
+}
+
+int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                      const void* res, void* y, hipStream_t st, const dm_gn_desc* g, const float* gamma,
+                      const float* beta, const float* ss, const float* pre, void* y_norm, float* mean,
+                      float* rstd) {
+  bool bn64;
+  int TR;
+  if (g) {
+    if (!gn_plan(d, g, bn64, TR)) return DM_ERR_UNSUPPORTED;
+  } else {
+    patch_plan(d, bn64, TR);
+  }
+  if (!TR) return DM_ERR_UNSUPPORTED;
+  const int H = d->Ho, W = d->Wo, Cin = d->C1 + d->C2;
+  const long M = (long)d->B * H * W;
 
   PatchArgs a;
   a.x1 = x1; a.x2 = x2; a.w = w; a.bias = bias; a.res = res; a.y = y;
@@ -384,6 +575,15 @@ int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, con
   a.x1_bytes = (unsigned)(npix_src * d->C1 * 2);
   a.x2_bytes = (unsigned)(npix_src * d->C2 * 2);
   a.w_bytes = (unsigned)((long)d->Cout * 9 * Cin * 2);
+  a.gn_y = nullptr;
+  a.gn_gamma = a.gn_beta = a.gn_ss = a.gn_pre = nullptr;
+  a.gn_mean = a.gn_rstd = nullptr;
+  a.gn_hw = a.gn_G = a.gn_cg = a.gn_act = 0;
+  a.gn_eps = 0.f;
+  if (g) {
+    a.gn_gamma = gamma; a.gn_beta = beta; a.gn_ss = ss; a.gn_pre = pre; a.gn_y = y_norm; a.gn_mean = mean; a.gn_rstd = rstd;
+    a.gn_hw = H * W; a.gn_G = g->G; a.gn_cg = d->Cout / g->G; a.gn_act = g->act; a.gn_eps = g->eps;
+  }
   a.n_mtiles = dm_cdiv((long)d->B * H, TR);
   const int mt_pad = (a.n_mtiles + 7) / 8 * 8;
   if (bn64) {

@@ -56,6 +56,8 @@ _SIGNATURES = {
     "dm_abi_version": (c_int, []),
     "dm_config_set": (c_int, [ctypes.c_char_p, c_int]),
     "dm_conv2d_igemm": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P]),
+    "dm_conv2d_gn_fusable": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(GnDesc)]),
+    "dm_conv2d_igemm_gn": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, ctypes.POINTER(GnDesc)] + [P] * 8),
     "dm_conv2d_wgrad_ws_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "dm_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, ctypes.c_size_t, P]),
     "dm_conv2d_wgrad_group_ws_bytes": (ctypes.c_size_t, [P, c_int]),

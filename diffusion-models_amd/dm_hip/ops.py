@@ -325,11 +325,22 @@ def _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, transposed, Ho
     return ConvDesc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, transposed, Ho, Wo)
 
 
+class FusedNorm:
+    """The GroupNorm (+ scale/shift or pre-add) (+ SiLU) that consumes a convolution's output, handed to conv2d so
+    that layers whose output tiles hold whole samples and groups produce it in the convolution's epilogue."""
+
+    def __init__(self, gamma, beta, groups, eps, act, scale_shift=None, pre_add=None):
+        self.gamma, self.beta, self.groups, self.eps, self.act = gamma, beta, int(groups), float(eps), bool(act)
+        self.scale_shift, self.pre_add = scale_shift, pre_add
+
+
 class _ConvFn(Function):
-    """y = conv2d(cat(x1, x2) [nearest-upsampled x2 if ups], weight) + bias + res"""
+    """y = conv2d(cat(x1, x2) [nearest-upsampled x2 if ups], weight) + bias + res
+    Returns (y, y_norm, mean, rstd): the last three are the fused GroupNorm's results when `norm` is given and the
+    layer qualifies, else None."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad=True, bias_twin=None):
+    def forward(ctx, x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad=True, bias_twin=None, norm=None):
         _require_device(x1, "conv2d")
         x1 = as_nhwc(x1)
         x2 = as_nhwc(x2) if x2 is not None else None
@@ -347,22 +358,48 @@ class _ConvFn(Function):
         y = empty_nhwc(B, Cout, Ho, Wo, x1.device)
         b32 = f32c(bias.detach()) if bias is not None else None
         d = _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, 0, Ho, Wo)
-        check(lib.dm_conv2d_igemm(ctypes.byref(d), x1.data_ptr(), _p(x2), w_fwd.data_ptr(), _p(b32), _p(res),
-                                  y.data_ptr(), _stream()))
+        y_norm = mean = rstd = None
+        if norm is not None:
+            ss, pre = norm.scale_shift, norm.pre_add
+            g = GnDesc(B, Ho * Wo, Cout, 0, norm.groups, norm.eps, int(norm.act), int(ss is not None),
+                       int(pre is not None))
+            if not lib.dm_conv2d_gn_fusable(ctypes.byref(d), ctypes.byref(g)):
+                norm = None
+        if norm is not None:
+            ss32 = f32c(ss.detach()) if ss is not None else None
+            pre32 = f32c(pre.detach()) if pre is not None else None
+            if ss32 is not None and tuple(ss32.shape) != (B, 2 * Cout):
+                raise RuntimeError(f"group_norm: scale_shift must be [{B}, {2 * Cout}], got {tuple(ss32.shape)}")
+            if pre32 is not None and tuple(pre32.shape) != (B, Cout):
+                raise RuntimeError(f"group_norm: pre_add must be [{B}, {Cout}], got {tuple(pre32.shape)}")
+            y_norm = empty_nhwc(B, Cout, Ho, Wo, x1.device)
+            mean = torch.empty((B, norm.groups), dtype=torch.float32, device=x1.device)
+            rstd = torch.empty((B, norm.groups), dtype=torch.float32, device=x1.device)
+            check(lib.dm_conv2d_igemm_gn(ctypes.byref(d), x1.data_ptr(), _p(x2), w_fwd.data_ptr(), _p(b32), _p(res),
+                                         y.data_ptr(), ctypes.byref(g), f32c(norm.gamma.detach()).data_ptr(),
+                                         f32c(norm.beta.detach()).data_ptr(), _p(ss32), _p(pre32), y_norm.data_ptr(),
+                                         mean.data_ptr(), rstd.data_ptr(), _stream()))
+            ctx.mark_non_differentiable(y_norm, mean, rstd)
+            ctx.set_materialize_grads(False)    # (no zero tensors made for the gradients of those three)
+        else:
+            check(lib.dm_conv2d_igemm(ctypes.byref(d), x1.data_ptr(), _p(x2), w_fwd.data_ptr(), _p(b32), _p(res),
+                                      y.data_ptr(), _stream()))
         ctx.save_for_backward(x1, x2, weight)
         ctx.params = (weight, bias)
         ctx.bias_twin = bias_twin
         ctx.cfg = (stride, pad, ups, pack, bias is not None and bias_grad, res is not None,
                    (B, C1, C2, Hs, Ws, Hi, Wi, Ho, Wo))
-        return y
+        return y, y_norm, mean, rstd
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         x1, x2, weight = ctx.saved_tensors
         stride, pad, ups, pack, has_bias, has_res, dims = ctx.cfg
         B, C1, C2, Hs, Ws, Hi, Wi, Ho, Wo = dims
         w4 = weight if weight.dim() == 4 else weight[:, :, None, None]
         Cout, Cin, KH, KW = w4.shape
+        if dy is None:
+            dy = torch.zeros((B, Cout, Ho, Wo), dtype=BF16, device=x1.device)
         dy = as_nhwc(dy)
         st = _stream()
         dx1 = dx2 = dw = db = None
@@ -438,21 +475,28 @@ class _ConvFn(Function):
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
         if dres is not None and (stream_w is not None or SIDE_WGRAD):
             SIDE_KEEP.append(dy)
-        return dx1, dx2, dw, db, dres, None, None, None, None, None, None
+        return dx1, dx2, dw, db, dres, None, None, None, None, None, None, None
 
 
-def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0, bias_grad=True, bias_twin=None):
+def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0, bias_grad=True, bias_twin=None,
+           norm=None):
     """bias_twin: the bias parameter of another convolution whose output is added to this one's (run with
     bias_grad=False): it receives this bias's gradient, the same column sums, from the same launch.
     bias_grad=False: the bias is added but its gradient is left to the consumer of the output (group_norm_act's
-    upstream_bias), which gets it for free."""
-    return _ConvFn.apply(x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad, bias_twin)
+    upstream_bias), which gets it for free.
+    norm: a FusedNorm describing the GroupNorm that consumes the output. The call then returns (y, done) where
+    done is (y_norm, mean, rstd) from the convolution's epilogue, to be passed to group_norm_act as `precomputed`,
+    or None when the layer does not qualify and the GroupNorm has to run as a launch of its own."""
+    y, y_norm, mean, rstd = _ConvFn.apply(x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad, bias_twin, norm)
+    if norm is None:
+        return y
+    return y, ((y_norm, mean, rstd) if y_norm is not None else None)
 
 
 # ------------------------------------------------------------------------------------------------------------
 class _GroupNormActFn(Function):
     @staticmethod
-    def forward(ctx, x1, x2, gamma, beta, ss, pre, G, eps, act, fork, upstream_bias):
+    def forward(ctx, x1, x2, gamma, beta, ss, pre, G, eps, act, fork, upstream_bias, precomputed=None):
         _require_device(x1, "group_norm")
         x1 = as_nhwc(x1)
         x2 = as_nhwc(x2) if x2 is not None else None
@@ -466,14 +510,21 @@ class _GroupNormActFn(Function):
             raise RuntimeError(f"group_norm: scale_shift must be [{B}, {2 * C}], got {tuple(ss32.shape)}")
         if pre32 is not None and tuple(pre32.shape) != (B, C):
             raise RuntimeError(f"group_norm: pre_add must be [{B}, {C}], got {tuple(pre32.shape)}")
-        y = empty_nhwc(B, C, H, W, x1.device)
-        mean = torch.empty((B, G), dtype=torch.float32, device=x1.device)
-        rstd = torch.empty((B, G), dtype=torch.float32, device=x1.device)
         d = GnDesc(B, H * W, C1, C2, G, eps, int(act), int(ss32 is not None), int(pre32 is not None))
-        ws = _scratch(x1.device, lib.dm_groupnorm_ws_floats(ctypes.byref(d)))
-        check(lib.dm_groupnorm_act_fwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
-                                       _p(ss32), _p(pre32), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                       ws.data_ptr(), _stream()))
+        if precomputed is not None:
+            # the convolution that produced x1 has normalised it in its epilogue (conv2d's `norm`)
+            y, mean, rstd = precomputed
+            if x2 is not None or tuple(y.shape) != (B, C, H, W) or tuple(mean.shape) != (B, G):
+                raise RuntimeError("group_norm: precomputed results do not belong to this input")
+            y = y.detach()
+        else:
+            y = empty_nhwc(B, C, H, W, x1.device)
+            mean = torch.empty((B, G), dtype=torch.float32, device=x1.device)
+            rstd = torch.empty((B, G), dtype=torch.float32, device=x1.device)
+            ws = _scratch(x1.device, lib.dm_groupnorm_ws_floats(ctypes.byref(d)))
+            check(lib.dm_groupnorm_act_fwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
+                                           _p(ss32), _p(pre32), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                           ws.data_ptr(), _stream()))
         ctx.save_for_backward(x1, x2, g32, b32, ss32, pre32, mean, rstd)
         ctx.params = (gamma, beta, upstream_bias)
         ctx.cfg = (d, B, C1, C2, H, W)
@@ -543,17 +594,20 @@ class _GroupNormActFn(Function):
         if direct:
             _grad_done(ctx.params[0])
             _grad_done(ctx.params[1])
-            return dx1, dx2, None, None, dss, dpre, None, None, None, None, dub
-        return dx1, dx2, dg, db_, dss, dpre, None, None, None, None, dub
+            return dx1, dx2, None, None, dss, dpre, None, None, None, None, dub, None
+        return dx1, dx2, dg, db_, dss, dpre, None, None, None, None, dub, None
 
 
 def group_norm_act(x1, gamma, beta, groups, eps, act, x2=None, scale_shift=None, pre_add=None, fork=False,
-                   upstream_bias=None):
+                   upstream_bias=None, precomputed=None):
     """With fork=True returns (y, x1', x2'): x1'/x2' are the inputs again, to be used by a second consumer whose
     gradient is then folded into this operator's backward kernel.
     upstream_bias: the bias parameter of the convolution whose output x1 is (and that was run with bias_grad=False):
-    its gradient, the sum of dx over samples and pixels, falls out of this operator's backward sums."""
-    return _GroupNormActFn.apply(x1, x2, gamma, beta, scale_shift, pre_add, groups, eps, act, fork, upstream_bias)
+    its gradient, the sum of dx over samples and pixels, falls out of this operator's backward sums.
+    precomputed: (y, mean, rstd) that conv2d(..., norm=FusedNorm(same arguments)) returned with x1: the forward
+    launch is skipped, the backward pass is the same."""
+    return _GroupNormActFn.apply(x1, x2, gamma, beta, scale_shift, pre_add, groups, eps, act, fork, upstream_bias,
+                                 precomputed)
 
 
 # ------------------------------------------------------------------------------------------------------------

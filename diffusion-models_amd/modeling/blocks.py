@@ -45,6 +45,11 @@ class ProjectedEmbeddings:
             self._side = None
 
     @property
+    def pending(self):
+        """Still being computed on another stream (nobody has joined it yet)."""
+        return self._side is not None
+
+    @property
     def raw(self):
         self.join()
         return self._raw
@@ -92,6 +97,23 @@ class ConvBlock(nn.Module):
             return norm(x, act=True, **kw)
         return self.nonlinearity(norm(x, act=False, **kw))
 
+    def _embedding_mix(self, embedding):
+        """norm2's share of the embedding: {} | {"pre_add": e} | {"scale_shift": e}."""
+        if self.emb_proj is None:
+            return {}
+        assert embedding is not None
+        e = None
+        if isinstance(embedding, ProjectedEmbeddings):
+            e = embedding.for_block(self)
+            embedding = embedding.raw
+        if e is not None:
+            pass
+        elif is_silu(self.nonlinearity):
+            e = self.emb_proj(embedding, act_in=True)
+        else:
+            e = self.emb_proj(self.nonlinearity(embedding))
+        return {"pre_add" if self.embedding_mixing == "addition" else "scale_shift": e}
+
     def forward(self, x: torch.Tensor, embedding: Optional[torch.Tensor] = None,
                 skip: Optional[torch.Tensor] = None):
         x = ops.as_nhwc(x)
@@ -103,24 +125,18 @@ class ConvBlock(nn.Module):
             h, x, skip = self.norm1(x, act=True, x2=skip, fork=True)
         else:
             h = self._norm_act(self.norm1, x, x2=skip)
-        # conv1's bias gradient is the sum of norm2's input gradient, which norm2's backward has at hand
-        h = self.conv1(h, bias_grad=False)
-
-        mix = {"upstream_bias": self.conv1.bias}
-        if self.emb_proj is not None:
-            assert embedding is not None
-            e = None
-            if isinstance(embedding, ProjectedEmbeddings):
-                e = embedding.for_block(self)
-                embedding = embedding.raw
-            if e is not None:
-                pass
-            elif is_silu(self.nonlinearity):
-                e = self.emb_proj(embedding, act_in=True)
-            else:
-                e = self.emb_proj(self.nonlinearity(embedding))
-            mix["pre_add" if self.embedding_mixing == "addition" else "scale_shift"] = e
-        h = self._norm_act(self.norm2, h, **mix)
+        # conv1's bias gradient is the sum of norm2's input gradient, which norm2's backward has at hand. Where conv1's
+        # output tiles hold whole samples (small images), norm2 runs in conv1's epilogue; it needs the embedding's
+        # projection for that, so a block that would have to wait for a projection still being computed on another
+        # stream (the first one) starts its convolution first and normalises in a launch of its own.
+        silu = is_silu(self.nonlinearity)
+        if isinstance(embedding, ProjectedEmbeddings) and embedding.pending:
+            h, done = self.conv1(h, bias_grad=False), None
+            mix = self._embedding_mix(embedding)
+        else:
+            mix = self._embedding_mix(embedding)
+            h, done = self.conv1(h, bias_grad=False, norm=self.norm2.fused(act=silu, **mix))
+        h = self._norm_act(self.norm2, h, upstream_bias=self.conv1.bias, precomputed=done, **mix)
         if self.training and self.dropout.p > 0:
             h = self.dropout(h)
 

@@ -84,6 +84,20 @@ typedef struct dm_conv_desc {
 int dm_conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
                     const void* res, void* y, void* stream);
 
+/* The convolution and the GroupNorm (+ per-sample scale/shift or pre-add) (+ SiLU) that follows it in ONE launch
+ * (modeling/blocks.py:51 -> :59-70: conv1, then norm2 mixed with the embedding, then the activation): on layers whose
+ * 256-pixel output tiles hold whole samples and whole groups (images of at most 16x16), the statistics and the
+ * normalised, activated tensor come out of the convolution's epilogue; y (the raw output, which the backward pass
+ * needs) is written as by dm_conv2d_igemm, y_norm / mean / rstd as by dm_groupnorm_act_fwd on y (statistics taken from
+ * the bf16-rounded y, pre_add folded in as there). g describes the GroupNorm over y (C1 = Cout, C2 = 0).
+ * dm_conv2d_gn_fusable tells whether a layer qualifies; dm_conv2d_igemm_gn fails with DM_ERR_UNSUPPORTED when it does not. */
+struct dm_gn_desc;
+int dm_conv2d_gn_fusable(const dm_conv_desc* d, const struct dm_gn_desc* g);
+int dm_conv2d_igemm_gn(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                       const void* res, void* y, const struct dm_gn_desc* g, const float* gamma, const float* beta,
+                       const float* scale_shift, const float* pre_add, void* y_norm, float* mean, float* rstd,
+                       void* stream);
+
 /* dw[n][tap][c] += sum_m dy[m][n] * X(m,tap)[c]; dw fp32 [Cout][KH*KW][C1+C2], ACCUMULATES.
  * ws: caller-provided scratch (16-byte aligned, at least dm_conv2d_wgrad_ws_bytes(d) bytes, contents irrelevant on
  * entry and on return). The split-K partial tiles go to the workspace with plain stores and a second kernel adds

@@ -350,6 +350,119 @@ def _groupnorm_case(B, C1, C2, H, W, act, ss, pre):
         assert rel_err(pred_.grad, prer.grad) < 2e-4
 
 
+CONV_GN_CASES = [
+    # B, C1, C2, Cout, H, W, ups, act, mix, fusable
+    (3, 128, 0, 256, 16, 16, 0, True, "pre", True),     # one sample per tile, 128-wide tiles, four threads per sum
+    (9, 256, 0, 256, 8, 8, 0, True, "pre", True),       # four samples per tile, ragged last tile
+    (8, 128, 128, 256, 8, 8, 0, True, "ss", True),      # skip concat into the conv, scale/shift mixing
+    (5, 64, 0, 64, 16, 16, 0, False, None, True),       # 64-wide tiles, no activation, no embedding
+    (4, 128, 0, 128, 8, 8, 1, True, "pre", True),       # through the fused upsampling gather (8x8 -> 16x16)
+    (2, 64, 0, 64, 32, 32, 0, True, "pre", False),      # a sample spans four tiles: separate launches
+    (4, 128, 0, 128, 4, 4, 0, True, "ss", False),       # sixteen samples per tile: more sums than threads
+    (2, 64, 0, 192, 16, 16, 0, True, None, False),      # 192 channels: groups of 6 do not tile 64 columns evenly
+]
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,H,W,ups,act,mix,fusable", CONV_GN_CASES)
+def test_conv_with_groupnorm_in_its_epilogue(B, C1, C2, Cout, H, W, ups, act, mix, fusable):
+    """conv2d(..., norm=FusedNorm) + group_norm_act(precomputed=...) against the same two operators as separate
+    launches (conv_gn_fuse=0) and against torch fp32. The raw convolution output is bit-identical; statistics agree
+    to fp32 summation order (1e-5), the normalised tensor to one bf16 rounding of values that agree to ~1e-6, the
+    gradients (same backward kernels, fed those statistics) to 1e-4 of their norm (1e-3 where they are bf16)."""
+    from dm_hip import lib, ops
+    rs = np.random.RandomState(B * 100 + Cout + H)
+    G = 32
+    Cin = C1 + C2
+    x1 = q(rnd(rs, B, C1, H, W))
+    x2 = q(rnd(rs, B, C2, H, W)) if C2 else None
+    w = q(rnd(rs, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5))
+    bias = 0.1 * rnd(rs, Cout)
+    gamma, beta = 1 + 0.2 * rnd(rs, Cout), 0.2 * rnd(rs, Cout)
+    e = {"pre": rnd(rs, B, Cout), "ss": 0.5 * rnd(rs, B, 2 * Cout), None: None}[mix]
+    Ho, Wo = H << ups, W << ups
+    gy = q(rnd(rs, B, Cout, Ho, Wo))
+    d = dev()
+
+    def run(fuse):
+        lib.dm_config_set(b"conv_gn_fuse", fuse)
+        try:
+            mk = lambda t: t.to(d).requires_grad_(True) if t is not None else None  # noqa: E731
+            t = dict(x1=mk(x1), x2=mk(x2), w=mk(w), bias=mk(bias), gamma=mk(gamma), beta=mk(beta), e=mk(e))
+            kw = {} if mix is None else {"pre_add" if mix == "pre" else "scale_shift": t["e"]}
+            pack = ops.WeightPack()
+            y, done = ops.conv2d(t["x1"].to(torch.bfloat16), t["w"], t["bias"], pack, x2=None if x2 is None else
+                                 t["x2"].to(torch.bfloat16), pad=1, ups=ups, bias_grad=False,
+                                 norm=ops.FusedNorm(t["gamma"], t["beta"], G, 1e-5, act, **kw))
+            assert (done is not None) == bool(fuse and fusable)
+            z = ops.group_norm_act(y, t["gamma"], t["beta"], G, 1e-5, act, upstream_bias=t["bias"],
+                                   precomputed=done, **kw)
+            z.backward(gy.to(d))
+            torch.cuda.synchronize()
+            stats = None if done is None else (done[1].clone(), done[2].clone())
+            return y.detach(), z.detach(), stats, {k: v.grad for k, v in t.items() if v is not None}
+        finally:
+            lib.dm_config_set(b"conv_gn_fuse", 1)
+
+    y0, z0, _, g0 = run(0)
+    y1, z1, stats, g1 = run(1)
+    assert torch.equal(y0, y1)
+    if fusable:
+        yf = y1.float() + (0 if mix != "pre" else e.to(d)[:, :, None, None])
+        grp = yf.reshape(B, G, -1)
+        assert rel_err(stats[0], grp.mean(2)) < 1e-5
+        assert rel_err(stats[1], (grp.var(2, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+        diff = (z0.float() - z1.float()).abs()
+        assert float(diff.max()) <= 2.0 ** -7 * max(1.0, float(z0.float().abs().max()))   # at most one bf16 step
+        assert float((diff > 0).float().mean()) < 2e-2
+        for k in g0:
+            # (bf16 gradients: statistics that differ in the last bits flip a rounding here and there)
+            assert rel_err(g1[k].float(), g0[k].float()) < (1e-3 if k in ("x1", "x2") else 1e-4), k
+    else:
+        assert torch.equal(z0, z1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+
+    # torch fp32 on the same bf16-rounded operands
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    v = q(F.conv2d(xin, w, bias, padding=1))
+    assert rel_err(y1.float().cpu(), v) < BF16_FWD
+    if mix == "pre":
+        v = v + e[:, :, None, None]
+    v = F.group_norm(v, G, gamma, beta, eps=1e-5)
+    if mix == "ss":
+        sc, sh = torch.chunk(e[:, :, None, None], 2, dim=1)
+        v = (1 + sc) * v + sh
+    v = F.silu(v) if act else v
+    assert rel_err(z1.float().cpu(), v) < 1.5 * BF16_FWD
+
+
+@pytest.mark.parametrize("H,Cout", [(16, 256), (8, 256)])
+def test_conv_groupnorm_epilogue_is_batch_independent(H, Cout):
+    """A batch of 128 takes 128-wide output tiles (16x16) or is steered to 64-wide ones to qualify (8x8), a batch of
+    3 takes 64-wide tiles: the normalised output and the statistics of a sample are the same bits in both, because
+    the sums over a sample's rows follow one order whatever the tile width."""
+    from dm_hip import ops
+    rs = np.random.RandomState(H)
+    B, Cin = 128 if H == 16 else 512, 64
+    d = dev()
+    x = q(rnd(rs, B, Cin, H, H)).to(d).to(torch.bfloat16)
+    w = q(rnd(rs, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5)).to(d)
+    bias, gamma, beta = (0.1 * rnd(rs, Cout)).to(d), (1 + 0.2 * rnd(rs, Cout)).to(d), (0.2 * rnd(rs, Cout)).to(d)
+    e = rnd(rs, B, Cout).to(d)
+    pack = ops.WeightPack()
+    with torch.no_grad():
+        out = []
+        for n in (B, 3):
+            y, done = ops.conv2d(x[:n].contiguous(memory_format=torch.channels_last), w, bias, pack, pad=1,
+                                 norm=ops.FusedNorm(gamma, beta, 32, 1e-5, True, pre_add=e[:n].contiguous()))
+            assert done is not None
+            out.append((y, *done))
+    for big, small in zip(*out):
+        assert torch.equal(big[:3], small)
+
+
 @pytest.mark.parametrize("mfma", [1, 0])
 @pytest.mark.parametrize("B,L,H,D", [(2, 64, 8, 8), (2, 49, 16, 8), (1, 256, 4, 16), (3, 16, 2, 32), (1, 100, 1, 64),
                                      (3, 70, 5, 16), (2, 1, 3, 8), (128, 64, 64, 8)])
