@@ -80,7 +80,7 @@ def _gn_elems(d):
 HBM_OPS = {
     "dm_groupnorm_act_fwd": ("gn_fwd (GroupNorm+scale/shift+SiLU forward)", lambda a: 4.0 * _gn_elems(a[0]._obj)),
     "dm_groupnorm_act_bwd": ("gn_bwd (GroupNorm+SiLU backward)",
-                             lambda a: (8.0 if a[10] else 6.0) * _gn_elems(a[0]._obj)),
+                             lambda a: (6.0 + 2.0 * bool(a[10]) + 2.0 * bool(a[11])) * _gn_elems(a[0]._obj)),
     "dm_colsum_bf16": ("colsum (conv bias gradient)", lambda a: 2.0 * a[2] * a[3]),
     "dm_colsum_bf16_dual": ("colsum (conv bias gradient)", lambda a: 2.0 * a[3] * a[4]),
     "dm_grad_norm": ("sumsq (global gradient norm)", lambda a: 4.0 * a[1]),
@@ -90,7 +90,7 @@ HBM_OPS = {
     "dm_mse_loss_bwd": ("mse_bwd (loss gradient)", lambda a: (16.0 if a[1] else 12.0) * a[5]),
     "dm_sampler_step": ("sampler_step (DDPM/DDIM/Euler update)", lambda a: (16.0 if a[2] else 12.0) * a[10]),
 }
-CONV_OPS = ("dm_conv2d_igemm", "dm_conv2d_wgrad", "dm_conv2d_wgrad_group")
+CONV_OPS = ("dm_conv2d_igemm", "dm_conv2d_igemm_gn", "dm_conv2d_wgrad", "dm_conv2d_wgrad_group")
 
 
 class AbiTimer:
@@ -125,7 +125,9 @@ class AbiTimer:
                 work = 2.0 * m * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
                 # algorithmic bytes: every operand once (input, weights, output, residual of the fused epilogue)
                 nbytes = 2.0 * (d.B * d.Hs * d.Ws * (d.C1 + d.C2) + d.Cout * d.KH * d.KW * (d.C1 + d.C2) + m * d.Cout)
-                if name == "dm_conv2d_igemm" and args[5]:
+                if name.startswith("dm_conv2d_igemm") and args[5]:
+                    nbytes += 2.0 * m * d.Cout
+                if name == "dm_conv2d_igemm_gn":    # the normalised tensor as well; flops: the convolution's only
                     nbytes += 2.0 * m * d.Cout
                 shape = (m, d.Cout, d.C1 + d.C2, d.KH, d.stride, d.ups, d.transposed)
             else:
@@ -483,7 +485,11 @@ def main():
             else:
                 get_sampler("euler", n_steps=3, pbar=False).sample(zz, sched, fake)
         summ = ct.summary()
-        ig = summ.get("dm_conv2d_igemm")
+        ig = {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0}
+        for key in ("dm_conv2d_igemm", "dm_conv2d_igemm_gn"):
+            for k, v in summ.get(key, {}).items():
+                ig[k] += v
+        fused_gn = summ.get("dm_conv2d_igemm_gn", {}).get("launches", 0)
         wg = {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0}
         for key in ("dm_conv2d_wgrad", "dm_conv2d_wgrad_group"):
             for k, v in summ.get(key, {}).items():
@@ -493,7 +499,9 @@ def main():
             traffic = measured_conv_traffic()
             roof = {"bound": "mfma",
                     "kernel": "conv_patch_kernel<128,6> / conv_patch_kernel<64,7> / conv_igemm_kernel<128>: every "
-                              "dm_conv2d_igemm launch of a step (forward + data gradient)",
+                              "dm_conv2d_igemm / dm_conv2d_igemm_gn launch of a step (forward + data gradient; "
+                              f"{fused_gn} of them carry the following GroupNorm in their epilogue, priced at the "
+                              "convolution's flops alone)",
                     "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "bytes/launch",

@@ -43,6 +43,7 @@ struct GnArgs {
   const float* pre;
   const bf16_t* dy;
   const bf16_t* dextra;
+  const bf16_t* dextra2;   // a second gradient to add (that of a skip connection's late consumer), or null
   bf16_t* y;
   bf16_t* dx1;
   bf16_t* dx2;
@@ -321,8 +322,9 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(GnArgs a) {
   const size_t base = (size_t)b * a.HW;
   auto emit = [&](const bf16x8_t& xr, const bf16x8_t& dr, int p) {
     const size_t o = (base + p) * a.C + c;
-    float f[8], e[8];
+    float f[8], e[8], e2[8];
     if (a.dextra) dm_unpack8(*(const bf16x8_t*)(a.dextra + o), e);
+    if (a.dextra2) dm_unpack8(*(const bf16x8_t*)(a.dextra2 + o), e2);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xv = (float)xr[j];
@@ -331,6 +333,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(GnArgs a) {
       // k * r = ua (u = ua * x + ub with ua = sc * gamma * r)
       const float dxv = ua[j] * du - xa[j] * (Ag[j] + xh * Bg[j]);
       f[j] = a.dextra ? dxv + e[j] : dxv;
+      if (a.dextra2) f[j] += e2[j];
     }
     const bf16x8_t ov = dm_pack8(f);
     if (c < a.C1) *(bf16x8_t*)(a.dx1 + (base + p) * a.C1 + c) = ov;
@@ -704,6 +707,9 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
     asm volatile("" : "+v"(xw[0]), "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]), "+v"(dw[0]), "+v"(dw[1]), "+v"(dw[2]), "+v"(dw[3]), "+v"(p));
     u32x4_t ew = {0, 0, 0, 0};
     if (EXTRA) ew = *(const u32x4_t*)(a.dextra + (base + (EXACT ? p : min(p, a.HW - 1))) * a.C + c);
+    const bool two = EXTRA && a.dextra2 != nullptr;
+    u32x4_t ew2 = {0, 0, 0, 0};
+    if (two) ew2 = *(const u32x4_t*)(a.dextra2 + (base + (EXACT ? p : min(p, a.HW - 1))) * a.C + c);
     u32x4_t ow;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -714,6 +720,7 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
       const f32x2_t xh = kxa * bf16_pair(xw[w]) + kxb;
       f32x2_t r = kua * bf16_pair(dw[w]) - kxa * (kA + xh * kB);
       if (EXTRA) r += bf16_pair(ew[w]);
+      if (two) r += bf16_pair(ew2[w]);
       ow[w] = pack_pair(r);
     }
     if (EXACT || p < a.HW) *(u32x4_t*)(dxb + (size_t)p * dxs) = ow;
@@ -877,8 +884,8 @@ extern "C" int dm_groupnorm_act_fwd_noalloc(const dm_gn_desc* d, const void* x1,
 extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma,
                                     const float* beta, const float* scale_shift, const float* pre_add,
                                     const float* mean, const float* rstd, const void* dy, const void* dextra,
-                                    void* dx1, void* dx2, float* dscale_shift, float* dpre_add, float* param_partials,
-                                    int want_upstream_bias, float* ws, void* stream) {
+                                    const void* dextra2, void* dx1, void* dx2, float* dscale_shift, float* dpre_add,
+                                    float* param_partials, int want_upstream_bias, float* ws, void* stream) {
   int rc = check_desc(d, "dm_groupnorm_act_bwd");
   if (rc) return rc;
   DM_REQUIRE(x1 && gamma && beta && mean && rstd && dy && dx1 && param_partials && ws, DM_ERR_ARG,
@@ -888,12 +895,14 @@ extern "C" int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const v
              "dm_groupnorm_act_bwd: scale_shift pointers disagree with the descriptor");
   DM_REQUIRE((d->has_pre != 0) == (pre_add != nullptr) && (d->has_pre != 0) == (dpre_add != nullptr), DM_ERR_ARG,
              "dm_groupnorm_act_bwd: pre_add pointers disagree with the descriptor");
-  DM_REQUIRE(((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dy | (uintptr_t)dextra | (uintptr_t)dx1 | (uintptr_t)dx2 | (uintptr_t)ws) % 16 == 0,
+  DM_REQUIRE(((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dy | (uintptr_t)dextra | (uintptr_t)dextra2 | (uintptr_t)dx1 |
+              (uintptr_t)dx2 | (uintptr_t)ws) % 16 == 0,
              DM_ERR_ARG, "dm_groupnorm_act_bwd: misaligned tensor");
+  DM_REQUIRE(!dextra2 || dextra, DM_ERR_ARG, "dm_groupnorm_act_bwd: dextra2 without dextra (pass a single addend as dextra)");
   GnArgs a = {};
   a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.pre = pre_add;
   a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
-  a.dy = (const bf16_t*)dy; a.dextra = (const bf16_t*)dextra;
+  a.dy = (const bf16_t*)dy; a.dextra = (const bf16_t*)dextra; a.dextra2 = (const bf16_t*)dextra2;
   a.dx1 = (bf16_t*)dx1; a.dx2 = (bf16_t*)dx2;
   DM_REQUIRE(!(want_upstream_bias && dextra), DM_ERR_ARG, "dm_groupnorm_act_bwd: the upstream bias gradient excludes dextra");
   a.dss = dscale_shift; a.dpre = dpre_add; a.pp = param_partials; a.want_dup = want_upstream_bias; a.ws = ws;

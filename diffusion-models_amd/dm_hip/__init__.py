@@ -79,7 +79,7 @@ _SIGNATURES = {
     "dm_noalloc_init": (c_int, []),
     "dm_groupnorm_noalloc_max_ws_floats": (c_long, []),
     "dm_groupnorm_act_fwd_noalloc": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 10),
-    "dm_groupnorm_act_bwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 15 + [c_int, P, P]),
+    "dm_groupnorm_act_bwd": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 16 + [c_int, P, P]),
     "dm_groupnorm_param_grads": (c_int, [ctypes.POINTER(GnDesc)] + [P] * 6),
     "dm_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "dm_attention_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),

@@ -325,6 +325,69 @@ def _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, transposed, Ho
     return ConvDesc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, transposed, Ho, Wo)
 
 
+class GradBox:
+    """Carries the gradient of a skip connection from its late consumer's backward (the up path, which runs first in
+    backward) to its early consumer's (the next layer of the down path), whose kernel adds it to the gradient it
+    computes - instead of autograd adding the two with a pass of its own. The early consumer creates the box for its
+    input tensor (grad_box), the late one routes the tensor through skip_tap."""
+    __slots__ = ("grad", "tapped", "delivered")
+
+    def __init__(self):
+        self.grad, self.tapped, self.delivered = None, False, False
+
+    def take(self, shape):
+        """The gradient left by the tap (None if the tensor was never tapped); the early consumer's backward calls it."""
+        if self.tapped and not self.delivered:
+            raise RuntimeError("skip connection: the early consumer's backward ran before the late consumer's "
+                               "(a gradient would be lost)")
+        g, self.grad = self.grad, None
+        self.tapped = self.delivered = False
+        if g is None:
+            return None
+        g = as_nhwc(g)
+        if tuple(g.shape) != tuple(shape) or g.dtype != BF16:
+            raise RuntimeError(f"skip connection: gradient {tuple(g.shape)} {g.dtype} does not match the input {tuple(shape)}")
+        return g
+
+
+SKIP_BOXES = os.environ.get("DM_SKIP_BOXES", "1") != "0"
+_BOX_KINDS = os.environ.get("DM_SKIP_BOX_KINDS", "gn,conv").split(",")
+
+
+def grad_box(x, kind="gn"):
+    """A box for the gradient that a later skip_tap of `x` (the same tensor object) will leave; None when gradients
+    are off or x needs none."""
+    if not (SKIP_BOXES and kind in _BOX_KINDS and torch.is_grad_enabled() and x.requires_grad):
+        return None
+    box = GradBox()
+    x._dm_grad_box = box
+    return box
+
+
+class _SkipTapFn(Function):
+    @staticmethod
+    def forward(ctx, x, box):
+        ctx.box = box
+        ctx.set_materialize_grads(False)
+        box.tapped, box.delivered = True, False
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.box.grad = g
+        ctx.box.delivered = True
+        return None, None
+
+
+def skip_tap(x):
+    """`x` for the late consumer of a skip connection: if an early consumer has left a box on the tensor, the gradient
+    this use produces goes into the box (and not to autograd's accumulation); else `x` as it is."""
+    box = getattr(x, "_dm_grad_box", None)
+    if box is None or box.tapped or not torch.is_grad_enabled():
+        return x
+    return _SkipTapFn.apply(x, box)
+
+
 class FusedNorm:
     """The GroupNorm (+ scale/shift or pre-add) (+ SiLU) that consumes a convolution's output, handed to conv2d so
     that layers whose output tiles hold whole samples and groups produce it in the convolution's epilogue."""
@@ -340,7 +403,8 @@ class _ConvFn(Function):
     layer qualifies, else None."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad=True, bias_twin=None, norm=None):
+    def forward(ctx, x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad=True, bias_twin=None, norm=None,
+                box=None):
         _require_device(x1, "conv2d")
         x1 = as_nhwc(x1)
         x2 = as_nhwc(x2) if x2 is not None else None
@@ -387,6 +451,9 @@ class _ConvFn(Function):
         ctx.save_for_backward(x1, x2, weight)
         ctx.params = (weight, bias)
         ctx.bias_twin = bias_twin
+        if box is not None and (ups or x2 is not None):
+            raise RuntimeError("conv2d: a gradient box needs a single, un-upsampled input")
+        ctx.box = box
         ctx.cfg = (stride, pad, ups, pack, bias is not None and bias_grad, res is not None,
                    (B, C1, C2, Hs, Ws, Hi, Wi, Ho, Wo))
         return y, y_norm, mean, rstd
@@ -414,7 +481,9 @@ class _ConvFn(Function):
             _, w_dgrad = pack.get(weight)
             dxf = empty_nhwc(B, Cin, Hi, Wi, dy.device)
             d = _conv_desc(B, Ho, Wo, Cout, 0, Cin, KH, KW, stride, pad, 0, 1, Hi, Wi)
-            check(lib.dm_conv2d_igemm(ctypes.byref(d), dy.data_ptr(), None, w_dgrad.data_ptr(), None, None,
+            # the gradient a skip connection's late consumer left for this input rides the epilogue's residual add
+            late = ctx.box.take((B, Cin, Hi, Wi)) if ctx.box is not None else None
+            check(lib.dm_conv2d_igemm(ctypes.byref(d), dy.data_ptr(), None, w_dgrad.data_ptr(), None, _p(late),
                                       dxf.data_ptr(), st))
             if ups:
                 dxs = empty_nhwc(B, Cin, Hs, Ws, dy.device)
@@ -475,19 +544,22 @@ class _ConvFn(Function):
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
         if dres is not None and (stream_w is not None or SIDE_WGRAD):
             SIDE_KEEP.append(dy)
-        return dx1, dx2, dw, db, dres, None, None, None, None, None, None, None
+        return dx1, dx2, dw, db, dres, None, None, None, None, None, None, None, None
 
 
 def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0, bias_grad=True, bias_twin=None,
-           norm=None):
+           norm=None, box=None):
     """bias_twin: the bias parameter of another convolution whose output is added to this one's (run with
     bias_grad=False): it receives this bias's gradient, the same column sums, from the same launch.
     bias_grad=False: the bias is added but its gradient is left to the consumer of the output (group_norm_act's
     upstream_bias), which gets it for free.
     norm: a FusedNorm describing the GroupNorm that consumes the output. The call then returns (y, done) where
     done is (y_norm, mean, rstd) from the convolution's epilogue, to be passed to group_norm_act as `precomputed`,
-    or None when the layer does not qualify and the GroupNorm has to run as a launch of its own."""
-    y, y_norm, mean, rstd = _ConvFn.apply(x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad, bias_twin, norm)
+    or None when the layer does not qualify and the GroupNorm has to run as a launch of its own.
+    box: a GradBox made for x1 (grad_box): the gradient it holds at backward time is added to x1's gradient in the
+    data-gradient kernel's epilogue."""
+    y, y_norm, mean, rstd = _ConvFn.apply(x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad, bias_twin, norm,
+                                          box)
     if norm is None:
         return y
     return y, ((y_norm, mean, rstd) if y_norm is not None else None)
@@ -496,8 +568,11 @@ def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0, bi
 # ------------------------------------------------------------------------------------------------------------
 class _GroupNormActFn(Function):
     @staticmethod
-    def forward(ctx, x1, x2, gamma, beta, ss, pre, G, eps, act, fork, upstream_bias, precomputed=None):
+    def forward(ctx, x1, x2, gamma, beta, ss, pre, G, eps, act, fork, upstream_bias, precomputed=None, box=None):
         _require_device(x1, "group_norm")
+        if box is not None and (x2 is not None or upstream_bias is not None):
+            raise RuntimeError("group_norm: a gradient box needs a single input and no upstream_bias")
+        ctx.box = box
         x1 = as_nhwc(x1)
         x2 = as_nhwc(x2) if x2 is not None else None
         B, C1, H, W = x1.shape
@@ -558,6 +633,10 @@ class _GroupNormActFn(Function):
                     dextra = da1  # the two gradients are the channel slices of one dense [B][HW][C] buffer
                 else:
                     dextra = as_nhwc(torch.cat([da1, da2], dim=1))
+        # the gradient a skip connection's late consumer left for x1: a second addend of the backward kernel
+        dextra2 = ctx.box.take((B, C1, H, W)) if ctx.box is not None else None
+        if dextra is None:
+            dextra, dextra2 = dextra2, None
         dx1 = empty_nhwc(B, C1, H, W, dev)
         dx2 = empty_nhwc(B, C2, H, W, dev) if x2 is not None else None
         gs, bs = _grad_sink(ctx.params[0]), _grad_sink(ctx.params[1])
@@ -581,7 +660,7 @@ class _GroupNormActFn(Function):
         partials = torch.empty((B, 3, C), dtype=torch.float32, device=dev)
         check(lib.dm_groupnorm_act_bwd(ctypes.byref(d), x1.data_ptr(), _p(x2), g32.data_ptr(), b32.data_ptr(),
                                        _p(ss32), _p(pre32), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(),
-                                       _p(dextra), dx1.data_ptr(), _p(dx2), _p(dss), _p(dpre), partials.data_ptr(),
+                                       _p(dextra), _p(dextra2), dx1.data_ptr(), _p(dx2), _p(dss), _p(dpre), partials.data_ptr(),
                                        int(dub is not None), ws.data_ptr(), _stream()))
         # the batch sums of the per-sample terms feed nothing but the optimizer: collected for one grouped launch
         # after backward when the gradients go straight to their buffers, else summed right here
@@ -594,20 +673,22 @@ class _GroupNormActFn(Function):
         if direct:
             _grad_done(ctx.params[0])
             _grad_done(ctx.params[1])
-            return dx1, dx2, None, None, dss, dpre, None, None, None, None, dub, None
-        return dx1, dx2, dg, db_, dss, dpre, None, None, None, None, dub, None
+            return dx1, dx2, None, None, dss, dpre, None, None, None, None, dub, None, None
+        return dx1, dx2, dg, db_, dss, dpre, None, None, None, None, dub, None, None
 
 
 def group_norm_act(x1, gamma, beta, groups, eps, act, x2=None, scale_shift=None, pre_add=None, fork=False,
-                   upstream_bias=None, precomputed=None):
+                   upstream_bias=None, precomputed=None, box=None):
     """With fork=True returns (y, x1', x2'): x1'/x2' are the inputs again, to be used by a second consumer whose
     gradient is then folded into this operator's backward kernel.
     upstream_bias: the bias parameter of the convolution whose output x1 is (and that was run with bias_grad=False):
     its gradient, the sum of dx over samples and pixels, falls out of this operator's backward sums.
     precomputed: (y, mean, rstd) that conv2d(..., norm=FusedNorm(same arguments)) returned with x1: the forward
-    launch is skipped, the backward pass is the same."""
+    launch is skipped, the backward pass is the same.
+    box: a GradBox made for x1 (grad_box): the gradient it holds at backward time is added to dx1 inside the backward
+    kernel."""
     return _GroupNormActFn.apply(x1, x2, gamma, beta, scale_shift, pre_add, groups, eps, act, fork, upstream_bias,
-                                 precomputed)
+                                 precomputed, box)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -9,6 +9,9 @@ CPU tensors, which is how the multi-process tests exercise it.
 """
 from typing import List, Sequence, Tuple
 
+import os
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -111,7 +114,10 @@ class BucketedAllReduce:
         for b in range(len(self.buckets)):
             if b not in self.launched:
                 self._launch(b, plain)
-        for h in self.handles:
+        debug = os.environ.get("DM_DDP_DEBUG") == "1"
+        for i, h in enumerate(self.handles):
+            if debug:
+                sys.stderr.write(f"[ddp rank {dist.get_rank(self.group) if self.have_group else 0}] wait {i}/{len(self.handles)}\n")
             h.wait()
         self.handles = []
         if self.world > 1:

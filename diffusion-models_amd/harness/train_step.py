@@ -12,7 +12,9 @@ do gradients, Adam moments and the EMA shadow. The optimizer tail is then two ke
 all-reduce over contiguous slices of the gradient arena, launched bucket by bucket (reverse registration order,
 the order gradients become ready) while backward is still running.
 """
+import contextlib
 import ctypes
+import sys
 import math
 import os
 from typing import Optional
@@ -101,6 +103,7 @@ class TrainStep:
         self._in_backward = False
         self._report = False   # backward in progress reports finished gradients to the reducer
         self._seg = None   # state of a segmented capture in progress (capture_segmented)
+        self._replay_stream = None
         self._sums = ops.SumCollector()
         if wgrad_group is None:
             # Layers per weight-gradient launch (<= 1: every layer launches its own, the default). Measured on the
@@ -313,19 +316,37 @@ class TrainStep:
             seg["after"].append([b for b in range(len(self.reducer.buckets)) if b not in self.reducer.launched])
         torch.cuda.current_stream().wait_stream(stream)
         self.segments = (seg["graphs"], seg["after"])
+        if os.environ.get("DM_DDP_DEBUG") == "1":
+            sys.stderr.write(f"[segments] {seg['after']}\n")
         return loss
 
     def replay_segmented(self):
-        """Replay the chain captured by capture_segmented() on the current stream, each bucket's all-reduce issued
-        right behind the graph that completes it; returns when every collective has been enqueued and the current
-        stream waits for all of them (gradients averaged)."""
+        """Replay the chain captured by capture_segmented(), each bucket's all-reduce issued right behind the graph
+        that completes it; returns when every collective has been enqueued and the current stream waits for all of
+        them (gradients averaged). The chain runs on a stream of its own, bracketed by waits against the current
+        stream, when that is the legacy default stream (whose implicit synchronisation with other streams does not
+        mix with graph launches interleaved with a collective library's copy streams)."""
         graphs, after = self.segments
-        self.reducer.begin()
-        for g, buckets in zip(graphs, after):
-            g.replay()
-            for b in buckets:
-                self.reducer.launch(b)
-        self.reducer.finish(plain=True)
+        cur = torch.cuda.current_stream()
+        own = None
+        if cur == torch.cuda.default_stream(cur.device) and os.environ.get("DM_REPLAY_OWN_STREAM", "1") != "0":
+            if self._replay_stream is None:
+                self._replay_stream = torch.cuda.Stream(cur.device)
+            own = self._replay_stream
+            own.wait_stream(cur)
+        with torch.cuda.stream(own) if own is not None else contextlib.nullcontext():
+            self.reducer.begin()
+            debug = os.environ.get("DM_DDP_DEBUG") == "2"
+            for i, (g, buckets) in enumerate(zip(graphs, after)):
+                g.replay()
+                if debug:
+                    torch.cuda.synchronize()
+                    sys.stderr.write(f"[replay] graph {i} done\n")
+                for b in buckets:
+                    self.reducer.launch(b)
+            self.reducer.finish(plain=True)
+        if own is not None:
+            cur.wait_stream(own)
 
     def _reduce(self):
         """Finish the data-parallel mean of the gradient arena (launches whatever buckets are still outstanding)."""

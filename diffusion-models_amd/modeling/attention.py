@@ -35,7 +35,9 @@ class Attention2D(nn.Module):
         B, C, H, W = x.shape
         L = H * W
         x = ops.as_nhwc(x)
-        h = self.norm(x)                                  # [B, C, H, W] pixel-major == tokens [B, L, C]
+        # the residual branch reads x through the norm's fork, so that its gradient is added inside the norm's backward
+        # kernel instead of by a separate accumulation pass
+        h, x, _ = self.norm(x, fork=True)                 # [B, C, H, W] pixel-major == tokens [B, L, C]
         qkv = self.qkv_proj(h)                            # [B, 3*inner, H, W] == tokens [B, L, (3, heads, d)]
         tokens = qkv.permute(0, 2, 3, 1).reshape(B, L, 3 * self.n_dim_inner)
         att = ops.attention(tokens, self.n_heads, self.n_dim_head)      # [B, L, inner]

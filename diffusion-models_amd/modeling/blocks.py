@@ -116,15 +116,17 @@ class ConvBlock(nn.Module):
 
     def forward(self, x: torch.Tensor, embedding: Optional[torch.Tensor] = None,
                 skip: Optional[torch.Tensor] = None):
+        # x may also feed a skip connection: the gradient its late consumer leaves in the box joins norm1's backward
+        box = ops.grad_box(x) if skip is None else None
         x = ops.as_nhwc(x)
-        skip = ops.as_nhwc(skip) if skip is not None else None
+        skip = ops.as_nhwc(ops.skip_tap(skip)) if skip is not None else None
 
         if is_silu(self.nonlinearity):
             # the residual branch reads x (and skip) through norm1's fork, so that its gradient is added inside
             # norm1's backward kernel
-            h, x, skip = self.norm1(x, act=True, x2=skip, fork=True)
+            h, x, skip = self.norm1(x, act=True, x2=skip, fork=True, box=box)
         else:
-            h = self._norm_act(self.norm1, x, x2=skip)
+            h = self._norm_act(self.norm1, x, x2=skip, box=box)
         # conv1's bias gradient is the sum of norm2's input gradient, which norm2's backward has at hand. Where conv1's
         # output tiles hold whole samples (small images), norm2 runs in conv1's epilogue; it needs the embedding's
         # projection for that, so a block that would have to wait for a projection still being computed on another
@@ -164,7 +166,7 @@ class DownsampleBlock(nn.Module):
 
     def forward(self, x):
         if isinstance(self.conv, Conv2d):
-            return self.conv(x)
+            return self.conv(x, box=ops.grad_box(x, "conv"))   # (x usually feeds a skip connection as well)
         return ops.avgpool2x(x)
 
 

@@ -23,11 +23,11 @@ class Conv2d(nn.Conv2d):
         self._pack = ops.WeightPack()
 
     def forward(self, x, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, ups: int = 0,
-                bias_grad: bool = True, bias_twin=None, norm=None):
+                bias_grad: bool = True, bias_twin=None, norm=None, box=None):
         """norm: a FusedNorm from GroupNorm.fused(...); the call then returns (y, precomputed-or-None), see
         ops.conv2d."""
         return ops.conv2d(x, self.weight, self.bias, self._pack, x2=x2, res=res, stride=self.stride[0],
-                          pad=self._pad, ups=ups, bias_grad=bias_grad, bias_twin=bias_twin, norm=norm)
+                          pad=self._pad, ups=ups, bias_grad=bias_grad, bias_twin=bias_twin, norm=norm, box=box)
 
 
 class Linear(nn.Linear):
@@ -53,10 +53,10 @@ class GroupNorm(nn.GroupNorm):
     second input tensor (channel concat) fused into one kernel."""
 
     def forward(self, x, act: bool = False, x2=None, scale_shift=None, pre_add=None, fork: bool = False,
-                upstream_bias=None, precomputed=None):
+                upstream_bias=None, precomputed=None, box=None):
         return ops.group_norm_act(x, self.weight, self.bias, self.num_groups, self.eps, act, x2=x2,
                                   scale_shift=scale_shift, pre_add=pre_add, fork=fork, upstream_bias=upstream_bias,
-                                  precomputed=precomputed)
+                                  precomputed=precomputed, box=box)
 
     def fused(self, act: bool = False, scale_shift=None, pre_add=None):
         """This layer as the epilogue of the convolution that produces its input (Conv2d's `norm`)."""

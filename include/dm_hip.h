@@ -214,7 +214,9 @@ long dm_groupnorm_noalloc_max_ws_floats(void);
 int dm_groupnorm_act_fwd_noalloc(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma,
                                  const float* beta, const float* scale_shift, const float* pre_add, void* y,
                                  float* mean, float* rstd, void* stream);
-/* dx1|dx2 bf16 (= GN backward + dextra, dextra optional bf16 [B][HW][C]); dscale_shift fp32 [B][2C] and dpre_add
+/* dx1|dx2 bf16 (= GN backward + dextra + dextra2, both optional bf16 [B][HW][C]: gradients that reach the same input
+ * by other routes - the residual branch of a block, a skip connection's second consumer - added here instead of by
+ * a pass of their own; dextra2 only together with dextra); dscale_shift fp32 [B][2C] and dpre_add
  * fp32 [B][C] are written when present. param_partials (fp32 [B][3][C], written): every sample's contribution to
  * dbeta ([b][0][c]), dgamma ([b][1][c]) and, when want_upstream_bias (excludes dextra), the sum of dx over the
  * sample's pixels ([b][2][c]): the bias gradient of the convolution whose output x is (modeling/blocks.py:51 -> :59)
@@ -224,8 +226,9 @@ int dm_groupnorm_act_fwd_noalloc(const dm_gn_desc* d, const void* x1, const void
  * another stream than the backward kernel, once that has finished: nothing but the optimizer consumes its results. */
 int dm_groupnorm_act_bwd(const dm_gn_desc* d, const void* x1, const void* x2, const float* gamma, const float* beta,
                          const float* scale_shift, const float* pre_add, const float* mean, const float* rstd,
-                         const void* dy, const void* dextra, void* dx1, void* dx2, float* dscale_shift,
-                         float* dpre_add, float* param_partials, int want_upstream_bias, float* ws, void* stream);
+                         const void* dy, const void* dextra, const void* dextra2, void* dx1, void* dx2,
+                         float* dscale_shift, float* dpre_add, float* param_partials, int want_upstream_bias,
+                         float* ws, void* stream);
 int dm_groupnorm_param_grads(const dm_gn_desc* d, const float* param_partials, float* dgamma, float* dbeta,
                              float* dupstream_bias, dm_sum_item* deferred, void* stream);
 

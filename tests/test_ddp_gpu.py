@@ -20,7 +20,7 @@ def _worker(rank, world, port, q, side_wgrad=1, segmented=False):
             sys.path.insert(0, p)
     from tests.parity import det_sd_for
     import faulthandler
-    faulthandler.dump_traceback_later(90, exit=True)   # a stuck rank says where, instead of a silent wait
+    faulthandler.dump_traceback_later(int(os.environ.get("DM_TEST_WATCHDOG", "90")), exit=True)   # a stuck rank says where, instead of a silent wait
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)

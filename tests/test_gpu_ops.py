@@ -463,6 +463,56 @@ def test_conv_groupnorm_epilogue_is_batch_independent(H, Cout):
         assert torch.equal(big[:3], small)
 
 
+@pytest.mark.parametrize("early", ["norm_fork", "norm", "conv_s2"])
+def test_skip_gradient_box(early):
+    """A tensor with two consumers: an early one (GroupNorm with / without the residual fork, or a stride-2 conv) and
+    a late one reached through skip_tap. With the box the late consumer's gradient is added inside the early
+    consumer's backward kernel; without it (boxes off) autograd adds the two. Both against torch fp32."""
+    from dm_hip import ops
+    rs = np.random.RandomState(5)
+    B, C, H = 3, 64, 16
+    x0 = q(rnd(rs, B, C, H, H))
+    gamma, beta = 1 + 0.2 * rnd(rs, C), 0.2 * rnd(rs, C)
+    w = q(rnd(rs, C, C, 3, 3, scale=(9 * C) ** -0.5))
+    late_w = q(rnd(rs, B, C, H, H))
+    go = q(rnd(rs, B, C, H // 2 if early == "conv_s2" else H, H // 2 if early == "conv_s2" else H))
+    d = dev()
+
+    def ours(boxes):
+        ops.SKIP_BOXES = boxes
+        try:
+            x = x0.to(d).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            xin = x * 1.0                          # a non-leaf, as in the network
+            g_, b_ = gamma.to(d).requires_grad_(True), beta.to(d).requires_grad_(True)
+            box = ops.grad_box(xin)
+            assert (box is not None) == boxes
+            if early == "conv_s2":
+                y = ops.conv2d(xin, w.to(d), None, ops.WeightPack(), stride=2, pad=1, box=box)
+            elif early == "norm_fork":
+                h, xa, _ = ops.group_norm_act(xin, g_, b_, 32, 1e-5, True, fork=True, box=box)
+                y = h + 0.5 * xa
+            else:
+                y = ops.group_norm_act(xin, g_, b_, 32, 1e-5, True, box=box)
+            tapped = ops.skip_tap(xin)
+            assert (tapped is not xin) == boxes
+            z = (tapped * late_w.to(d).to(torch.bfloat16)).float().sum()
+            (y.float() * go.to(d)).sum().add(z).backward()
+            return x.grad.float().cpu()
+        finally:
+            ops.SKIP_BOXES = True
+
+    xr = x0.clone().requires_grad_(True)
+    if early == "conv_s2":
+        yr = F.conv2d(xr, w, None, stride=2, padding=1)
+    else:
+        hr = F.silu(F.group_norm(xr, 32, gamma, beta, eps=1e-5))
+        yr = hr + 0.5 * xr if early == "norm_fork" else hr
+    ((yr * go).sum() + (xr * late_w).sum()).backward()
+    on, off = ours(True), ours(False)
+    assert rel_err(on, xr.grad) < BF16_BWD and rel_err(off, xr.grad) < BF16_BWD
+    assert rel_err(on, off) < BF16_FWD
+
+
 @pytest.mark.parametrize("mfma", [1, 0])
 @pytest.mark.parametrize("B,L,H,D", [(2, 64, 8, 8), (2, 49, 16, 8), (1, 256, 4, 16), (3, 16, 2, 32), (1, 100, 1, 64),
                                      (3, 70, 5, 16), (2, 1, 3, 8), (128, 64, 64, 8)])
