@@ -445,21 +445,26 @@ def main():
         finally:
             ops.FORCE_REPACK = False
 
-    for _ in range(args.warmup):
-        run()
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # the steps run on a stream of the benchmark's own, not the legacy default stream (whose implicit synchronisation
+    # with other streams is best kept away from graph launches interleaved with a collective library's streams)
+    bench_stream = torch.cuda.Stream()
+    bench_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(bench_stream):
+        for _ in range(args.warmup):
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    torch.cuda.current_stream().wait_stream(bench_stream)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
