@@ -699,17 +699,27 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
   }
   bf16_t* const dxb = c < a.C1 ? a.dx1 + base * a.C1 + c : a.dx2 + base * a.C2 + (c - a.C1);
   const int dxs = c < a.C1 ? a.C1 : a.C2;
+  // The addends are read AHEAD pixels in front of their use (a window of registers, the slab has taken the rest): a
+  // load per pixel issued where it is needed would put its full latency into every iteration.
+  constexpr int AHEAD = PPT > 2 ? 2 : 1;
+  const bool two = EXTRA && a.dextra2 != nullptr;
+  u32x4_t ew[PPT], ew2[PPT];
+  auto fetch = [&](int i, int p) {
+    const size_t o = (base + (EXACT ? p : min(p, a.HW - 1))) * a.C + c;
+    ew[i] = *(const u32x4_t*)(a.dextra + o);
+    if (two) ew2[i] = *(const u32x4_t*)(a.dextra2 + o);
+  };
+  if (EXTRA) {
+#pragma unroll
+    for (int i = 0; i < AHEAD && i < PPT; ++i) fetch(i, pl + i * PLN);
+  }
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     int p = pl + i * PLN;
     unsigned xw[4] = {xr[i][0], xr[i][1], xr[i][2], xr[i][3]}, dw[4] = {dr[i][0], dr[i][1], dr[i][2], dr[i][3]};
     // opaque: unpacking and address arithmetic stay with their pixel instead of being hoisted for the whole slab
     asm volatile("" : "+v"(xw[0]), "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]), "+v"(dw[0]), "+v"(dw[1]), "+v"(dw[2]), "+v"(dw[3]), "+v"(p));
-    u32x4_t ew = {0, 0, 0, 0};
-    if (EXTRA) ew = *(const u32x4_t*)(a.dextra + (base + (EXACT ? p : min(p, a.HW - 1))) * a.C + c);
-    const bool two = EXTRA && a.dextra2 != nullptr;
-    u32x4_t ew2 = {0, 0, 0, 0};
-    if (two) ew2 = *(const u32x4_t*)(a.dextra2 + (base + (EXACT ? p : min(p, a.HW - 1))) * a.C + c);
+    if (EXTRA && i + AHEAD < PPT) fetch(i + AHEAD, p + AHEAD * PLN);   // (address from the opaque p: stays here)
     u32x4_t ow;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -719,8 +729,8 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
       const f32x2_t kA = {Ag[h][2 * q], Ag[h][2 * q + 1]}, kB = {Bg[h][2 * q], Bg[h][2 * q + 1]};
       const f32x2_t xh = kxa * bf16_pair(xw[w]) + kxb;
       f32x2_t r = kua * bf16_pair(dw[w]) - kxa * (kA + xh * kB);
-      if (EXTRA) r += bf16_pair(ew[w]);
-      if (two) r += bf16_pair(ew2[w]);
+      if (EXTRA) r += bf16_pair(ew[i][w]);
+      if (two) r += bf16_pair(ew2[i][w]);
       ow[w] = pack_pair(r);
     }
     if (EXACT || p < a.HW) *(u32x4_t*)(dxb + (size_t)p * dxs) = ow;
