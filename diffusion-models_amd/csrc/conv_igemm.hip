@@ -35,6 +35,10 @@ struct ConvArgs {
   int KH, KW, stride, pad, ups, transposed;
   int M, n_mtiles, n_ntiles;
   unsigned x1_bytes, x2_bytes, w_bytes;
+  // Data gradient of a 3x3 / stride-2 / pad-1 convolution onto an even-sized image: an output pixel only meets the
+  // taps whose parity matches its own (1, 2, 2 or 4 of the 9), so the rows of a tile are taken from ONE parity class
+  // (tile mt -> class mt / tpc, rows in class-major order) and the tile runs that class's taps only.
+  int subpix, tpc, Mq;
 };
 
 template <int BN>
@@ -59,7 +63,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(ConvArgs a) {
   int mt, nt;
   dm_xcd_tile(blockIdx.x, a.n_ntiles, mt, nt);
   if (mt >= a.n_mtiles) return;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int n0 = nt * BN;
+  const int cls = a.subpix ? mt / a.tpc : 0;
+  const int m0 = (a.subpix ? mt - cls * a.tpc : mt) * BM;     // first row within the class (or of the whole tensor)
+  const int py = cls >> 1, px = cls & 1;
+  // row of the tile -> output pixel index (-1: none)
+  auto row_pixel = [&](int row) -> int {
+    const int m = m0 + row;
+    if (!a.subpix) return m < a.M ? m : -1;
+    if (m >= a.Mq) return -1;
+    const int hq = a.Ho >> 1, wq = a.Wo >> 1;
+    const int b = m / (hq * wq), r = m - b * (hq * wq);
+    const int yq = r / wq, xq = r - yq * wq;
+    return (b * a.Ho + 2 * yq + py) * a.Wo + 2 * xq + px;
+  };
+  // the taps a tile runs: all of them, or those of its parity class (kernel row kh meets output row oh iff
+  // oh + pad - kh is even: kh = 1 for even rows, kh = 0 and 2 for odd ones; columns alike)
+  const int kh_begin = a.subpix ? (py ? 0 : 1) : 0, kw_begin = a.subpix ? (px ? 0 : 1) : 0;
+  const int k_step = a.subpix ? 2 : 1;
+  const int n_taps = a.subpix ? (py ? 2 : 1) * (px ? 2 : 1) : a.KH * a.KW;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -77,8 +99,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(ConvArgs a) {
   int rb[4], rh[4], rw_[4];                        // image index * Hs, oh/ow pre-offset; rb < 0: row beyond M
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int m = m0 + srow + 32 * i;
-    if (m < a.M) {
+    const int m = row_pixel(srow + 32 * i);
+    if (m >= 0) {
       int hw = a.Ho * a.Wo;
       int b = m / hw, r = m - b * hw;
       int oh = r / a.Wo, ow = r - oh * a.Wo;
@@ -97,7 +119,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(ConvArgs a) {
   }
 
   // staging cursor (tap, channel offset) and the source pixel of each of the 4 rows for that tap
-  int s_kh = 0, s_kw = 0, s_cc = 0;
+  int s_kh = kh_begin, s_kw = kw_begin, s_cc = 0;
   int pix[4];
   auto set_tap = [&]() {
 #pragma unroll
@@ -146,7 +168,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(ConvArgs a) {
     s_cc += BK;
     if (s_cc >= a.Cin) {
       s_cc = 0;
-      if (++s_kw == a.KW) { s_kw = 0; ++s_kh; }
+      s_kw += k_step;
+      if (s_kw >= a.KW) { s_kw = kw_begin; s_kh += k_step; }
       set_tap();
     }
   };
@@ -174,7 +197,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(ConvArgs a) {
     }
   }
 
-  const int nsteps = a.KH * a.KW * (a.Cin / BK);
+  const int nsteps = n_taps * (a.Cin / BK);
   stage(0);
   for (int s = 0; s < nsteps; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -214,8 +237,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(ConvArgs a) {
   for (int it = 0; it < (BM * CPR) / NTHREADS; ++it) {
     int item = tid + NTHREADS * it;
     int row = item / CPR, cch = item - row * CPR;
-    int m = m0 + row, n = n0 + cch * 8;
-    if (m < a.M && n < a.Cout) {
+    const int m = row_pixel(row), n = n0 + cch * 8;
+    if (m >= 0 && n < a.Cout) {
       const float* src = ep + row * S::EP_PITCH + cch * 8;
       f32x4_t v0 = *(const f32x4_t*)src, v1 = *(const f32x4_t*)(src + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -244,6 +267,7 @@ int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, con
 int dm_conv_patch_gn_ok(const dm_conv_desc* d, const dm_gn_desc* g);
 extern int g_dm_use_patch_kernel;
 extern int g_dm_conv_gn_fuse;
+extern int g_dm_dgrad_subpixel;
 
 static int conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
                         const void* res, void* y, void* stream, const dm_gn_desc* g, const float* gamma,
@@ -323,6 +347,14 @@ static int conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, c
   a.x2_bytes = (unsigned)(npix_src * d->C2 * 2);
   a.w_bytes = (unsigned)wbytes;
   a.n_mtiles = dm_cdiv(M, BM);
+  a.subpix = 0; a.tpc = 0; a.Mq = 0;
+  if (g_dm_dgrad_subpixel && d->transposed && d->stride == 2 && d->KH == 3 && d->KW == 3 && d->pad == 1 &&
+      d->Ho % 2 == 0 && d->Wo % 2 == 0) {
+    a.subpix = 1;
+    a.Mq = (int)(M / 4);
+    a.tpc = dm_cdiv(a.Mq, BM);
+    a.n_mtiles = 4 * a.tpc;
+  }
   const int mt_pad = (a.n_mtiles + 7) / 8 * 8;
   hipStream_t st = (hipStream_t)stream;
   if (d->Cout % 128 == 0 || d->Cout > 128) {

@@ -54,6 +54,8 @@ CONV_CASES += [
     (3, 64, 0, 64, 28, 28, 3, 1, 0),        # tiles straddle image boundaries at arbitrary rows
     (11, 128, 0, 64, 7, 7, 3, 1, 0),
     (2, 64, 0, 64, 8, 8, 3, 1, 1),          # fused upsample through the patch path
+    (5, 128, 0, 64, 32, 32, 3, 2, 0),       # stride 2 on an even size: the data gradient runs by pixel parity class
+    (3, 64, 0, 128, 12, 20, 3, 2, 0),       # ... classes of 90 pixels: a ragged tile per class
 ]
 
 
@@ -63,11 +65,13 @@ def test_conv2d_fwd_bwd(B, C1, C2, Cout, H, W, k, stride, ups, patch):
     from dm_hip import ops, lib
     lib.dm_config_set(b"conv_patch", patch)
     lib.dm_config_set(b"wgrad_row3", patch)   # patch=0 also selects the single-tap weight-gradient kernel
+    lib.dm_config_set(b"dgrad_subpixel", patch)   # ... and the stride-2 data gradient over all nine taps
     try:
         _conv2d_case(B, C1, C2, Cout, H, W, k, stride, ups)
     finally:
         lib.dm_config_set(b"conv_patch", 1)
         lib.dm_config_set(b"wgrad_row3", 1)
+        lib.dm_config_set(b"dgrad_subpixel", 1)
 
 
 def _conv2d_case(B, C1, C2, Cout, H, W, k, stride, ups):
