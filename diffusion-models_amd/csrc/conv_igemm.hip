@@ -357,7 +357,9 @@ static int conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, c
   }
   const int mt_pad = (a.n_mtiles + 7) / 8 * 8;
   hipStream_t st = (hipStream_t)stream;
-  if (d->Cout % 128 == 0 || d->Cout > 128) {
+  // 128-wide tiles, unless the output is narrow or 128-wide tiles would leave CUs without a workgroup
+  const bool few = (long)a.n_mtiles * dm_cdiv(d->Cout, 128) < 200 && d->Cout % 64 == 0;
+  if ((d->Cout % 128 == 0 || d->Cout > 128) && !few) {
     a.n_ntiles = dm_cdiv(d->Cout, 128);
     hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(mt_pad * a.n_ntiles), dim3(NTHREADS), 0, st, a);
   } else {
