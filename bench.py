@@ -17,6 +17,12 @@ import os
 import sys
 import time
 
+# Hardware queues per process (HIP's default is 4), read when the runtime library loads. A step uses a main stream,
+# one or two side streams, an auxiliary one, the graph's own and the collective library's: with more streams than
+# hardware queues, unrelated streams share a queue and wait behind each other's barriers. (No effect on the one-GPU
+# numbers: 9.00 ms/step with 4 and with 8.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "diffusion-models_amd")
 for p in (ROOT, PKG):
@@ -46,7 +52,7 @@ def load_cfg(name):
         return json.load(f)
 
 
-def build_step(cfg, device, use_ema=True):
+def build_step(cfg, device, use_ema=True, bucket_mb=25):
     from modeling import get_model
     from diffusion.scheduler import get_scheduler
     from harness.train_step import TrainStep
@@ -55,7 +61,7 @@ def build_step(cfg, device, use_ema=True):
     sched = get_scheduler(cfg["scheduler_type"], **cfg["scheduler_cfg"])
     step = TrainStep(model, sched, lr=cfg["lr"], betas=(0.9, 0.99), clip_grad_norm=cfg.get("clip_grad_norm", 1.0),
                      use_ema=cfg.get("use_ema", True) and use_ema, ema_inv_gamma=cfg.get("ema_inv_gamma", 1.0),
-                     ema_power=cfg.get("ema_power", 0.75), p_uncond=cfg.get("p_uncond", 0.2))
+                     ema_power=cfg.get("ema_power", 0.75), p_uncond=cfg.get("p_uncond", 0.2), bucket_mb=bucket_mb)
     return model, sched, step
 
 
@@ -345,6 +351,7 @@ def main():
                     help="one GPU: create an RCCL process group of one rank and run the data-parallel collectives "
                          "(implies --split-graph)")
     ap.add_argument("--pg-port", type=int, default=29731)
+    ap.add_argument("--bucket-mb", type=int, default=25, help="gradient all-reduce bucket size (MiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--mode", choices=["train", "sample"], default="train",
@@ -360,6 +367,9 @@ def main():
                     help="streams the weight-gradient kernels rotate over beside the main one (0: none; default: the harness's)")
     args = ap.parse_args()
 
+    if os.environ.get("DM_BENCH_WATCHDOG"):    # a stuck rank says where: Python stacks to stderr every N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DM_BENCH_WATCHDOG"]), repeat=True)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -368,6 +378,10 @@ def main():
         args.split_graph = True
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # Everything runs on a stream of the benchmark's own, not the legacy default stream: that one synchronises
+    # implicitly with other streams, which does not mix with a collective library's streams working between the
+    # launches (two ranks over gloo replaying the graph chain on it hung; never on a created stream).
+    torch.cuda.set_stream(torch.cuda.Stream(device))
     if world > 1 or args.force_collectives:
         # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the one JSON
         # line by pointing file descriptor 1 at stderr for the run; emit() writes to the saved descriptor
@@ -388,7 +402,7 @@ def main():
     if args.mode == "sample":
         return bench_sampling(args, cfg, device, rank, world)
     batch = args.batch or cfg["batch_size"]
-    model, sched, step = build_step(cfg, device)
+    model, sched, step = build_step(cfg, device, bucket_mb=args.bucket_mb)
     if args.side_streams is not None:
         step.side_wgrad = args.side_streams
     x, cls = synthetic_batch(cfg, rank, device, batch)
@@ -451,20 +465,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # the steps run on a stream of the benchmark's own, not the legacy default stream (whose implicit synchronisation
-    # with other streams is best kept away from graph launches interleaved with a collective library's streams)
-    bench_stream = torch.cuda.Stream()
-    bench_stream.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(bench_stream):
-        for _ in range(args.warmup):
-            run()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        barrier()
-        elapsed = time.perf_counter() - t0
-    torch.cuda.current_stream().wait_stream(bench_stream)
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -478,6 +486,7 @@ def main():
     roof, hbm, summ = None, None, {}
     if rank == 0:
         step.side_wgrad = 0
+        step.reducer.enabled = False     # this rank's own step: the other ranks run no collectives beside it
         with AbiTimer() as ct:
             step.step(x, cls)
             # the sampler update kernels: three eager steps of each family on a generation-sized batch

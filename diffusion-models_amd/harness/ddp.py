@@ -39,6 +39,7 @@ class BucketedAllReduce:
         # for a single rank too: with a process group of one rank the collectives then really run (a way to exercise
         # the RCCL path on a one-GPU box), without a process group only on_bucket is called.
         self.force = False
+        self.enabled = True    # False: no collectives at all (a rank that runs a step of its own, e.g. to time kernels)
         # Optional callable(bucket index): called INSTEAD of launching the bucket's all-reduce when the bucket becomes
         # complete during backward (used to cut a HIP-graph capture there; the collective is issued at replay).
         self.on_bucket = None
@@ -77,7 +78,7 @@ class BucketedAllReduce:
 
     @property
     def active(self):
-        return self.world > 1 or self.force
+        return self.enabled and (self.world > 1 or self.force)
 
     def launch(self, b):
         """All-reduce bucket b now, ordered after the current stream only (replay of captured graph segments: the

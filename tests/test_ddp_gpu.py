@@ -75,6 +75,9 @@ def _worker(rank, world, port, q, side_wgrad=1, segmented=False):
 
 
 def _run(world, port, side_wgrad=1, segmented=False):
+    # (read when the HIP runtime loads in the workers: the ranks share one GPU here and each uses more streams -
+    # main, side, auxiliary, graph-internal, gloo's copy streams - than the default of four hardware queues)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, side_wgrad, segmented)) for r in range(world)]

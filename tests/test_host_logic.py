@@ -164,3 +164,14 @@ def test_fid_extrapolation_and_frechet_distance():
     assert np.allclose(r["fids"], fids) and abs(r["fid_infinity"] - fit.intercept) < 1e-12
     assert abs(r["fid_target"] - (fit.slope / 50_000 + fit.intercept)) < 1e-12
     assert r["subset_sizes"] == sizes and 0 <= r["regression"]["r_squared"] <= 1
+
+
+def test_bench_command_line_parses():
+    """bench.py's argument parser builds (a duplicated option would only show when the driver starts the benchmark)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
