@@ -20,6 +20,7 @@
 #include "dm_common.h"
 
 extern int g_dm_use_wgrad3;
+extern int g_dm_use_wgrad9;
 extern int g_dm_wgrad_slab_overhead;
 extern int g_dm_wgrad_reduce_cap;
 
@@ -607,6 +608,278 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad3_kernel(WgradArgs a) {
   wgrad3_body<NST>(a, logical);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// All NINE taps of a 3x3 / stride 1 / pad 1 layer in one workgroup, on a 128 (co) x 32 (ci) tile. A 64-pixel step is
+// RS = 64 / Wo whole output rows of ONE image; the RS + 2 input rows they need are staged once with their left/right
+// halo and serve every tap, so a step moves the bytes of the three-tap kernel's step (dy 16 KB + <= 9 KB of input)
+// for 1.5 x its MFMAs, and the dy fragments are shared by nine taps instead of three. Patch pixels are 64-byte rows
+// (32 channels = two 32-byte halves); the halves of pixel pp swap places when bit 3 of pp is set (8-wide images: when
+// the patch row is odd), so the 4 + 4 pixel rows that half a wave touches in one transposing read fall on different
+// banks whatever the tap. Fragment reads run one kernel row ahead of the MFMAs inside the step.
+constexpr int SLAB9_FLOATS = 9 * 128 * 32;
+
+template <int N>
+__device__ __forceinline__ void wait9(s16x4_t (&a)[4], s16x4_t (&b)[4], s16x4_t (&c)[3], s16x4_t (&d)[3]) {
+  asm volatile("s_waitcnt lgkmcnt(%14)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                 "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2])
+               : "n"(N));
+}
+
+template <int NST>
+__device__ __forceinline__ void wgrad9_body(const WgradArgs& a, const int logical) {
+  constexpr int NT = 512, TCO = 128, TCI = 32;
+  using TY = Tile<TCO, NT>;                       // dy tile: 64 pixels x 128 channels
+  constexpr int XBYTES = 16384;                   // patch region: every thread issues two 16-byte pieces; <= 9 KB used
+  constexpr int STAGE = TY::BYTES + XBYTES;
+  constexpr int XPIECES = 2;
+  constexpr int LPS = TY::PIECES + XPIECES;
+  constexpr int EP_TAPS = 5;                      // epilogue: one wave group's accumulators, five taps at a time, so
+  constexpr int EP_BYTES = EP_TAPS * 4 * 256 * 16;   // that the ring decides the LDS footprint (what is left of the
+  constexpr int TOTAL = (NST * STAGE > EP_BYTES) ? NST * STAGE : EP_BYTES;   // CU's LDS takes the HBM-bound kernels
+  constexpr int MI = 4;                           // of the other stream); wave tile 64 (co) x 16 (ci)
+  __shared__ __attribute__((aligned(16))) char smem[TOTAL];
+
+  const int per = a.n_co_tiles * a.n_ci_tiles;
+  const int ks = logical / per;
+  const int inner = logical - ks * per;
+  const int tco = inner / a.n_ci_tiles, tci = inner - tco * a.n_ci_tiles;
+  const int co0 = tco * TCO, ci0 = tci * TCI;
+  const bool second = ci0 >= a.C1;
+  const int csrc = second ? a.C2 : a.C1;
+  const int cioff = second ? ci0 - a.C1 : ci0;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+
+  __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(second ? a.x2 : a.x1), 0,
+                                                                 second ? a.x2_bytes : a.x1_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
+
+  const int m_begin = ks * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+  const int nsteps = (m_end - m_begin + BKM - 1) / BKM;
+  const int PW = a.Wo + 2, RS = BKM / a.Wo, npatch = (RS + 2) * PW;
+  const bool narrow = a.Wo == 8;
+  auto half_key = [&](int pp, int prow) { return narrow ? ((prow & 1) << 1) : (((pp >> 3) & 1) << 1); };
+
+  // dy staging (as in the other kernels)
+  const int yrow = tid / TY::PPR, yslot = tid % TY::PPR;
+  const int ypiece = yslot ^ swz<TY::PPR>(yrow);
+  const bool ycol_ok = co0 + ypiece * 8 < a.Cout;
+  unsigned yoff[TY::PIECES];
+#pragma unroll
+  for (int i = 0; i < TY::PIECES; ++i)
+    yoff[i] = (unsigned)(((m_begin + yrow + TY::ROW_STEP * i) * a.Cout + co0 + ypiece * 8) * 2);
+  const unsigned ystep = (unsigned)(BKM * a.Cout * 2);
+
+  // patch staging: piece idx = tid + 512 i -> patch pixel idx / 4 (row prow incl. the two halo rows, column pcol incl.
+  // halo), 16-byte slot idx % 4
+  int xprow[XPIECES], xcol[XPIECES], xconst[XPIECES];
+#pragma unroll
+  for (int i = 0; i < XPIECES; ++i) {
+    const int idx = tid + NT * i, pp = idx >> 2, slot = idx & 3;
+    const int prow = pp / PW, pcol = pp - prow * PW;
+    const int iw = pcol - 1;
+    xprow[i] = prow;
+    xcol[i] = (pp < npatch && iw >= 0 && iw < a.Wi) ? (iw >> a.ups) : -1;
+    xconst[i] = (cioff + ((slot ^ half_key(pp, prow)) << 3)) * 2;
+  }
+  const int csrc2 = csrc * 2;
+  // the step's first output row: image and row within it (a step never leaves its image: Ho is a multiple of RS)
+  int img = (m_begin / a.Wo) / a.Ho;
+  int row0 = m_begin / a.Wo - img * a.Ho;
+
+  auto stage = [&](int step) {  // called with step = 0, 1, 2, ... in order
+    char* sy = smem + (step % NST) * STAGE;
+    char* sx = sy + TY::BYTES;
+    const int mb = m_begin + step * BKM;
+#pragma unroll
+    for (int i = 0; i < TY::PIECES; ++i) {
+      const int m = mb + yrow + TY::ROW_STEP * i;
+      const unsigned off = (m < m_end && ycol_ok) ? yoff[i] : DM_OOB;
+      yoff[i] += ystep;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, DM_LDS(sy + (wave * 64 + NT * i) * 16), 16, off, 0, 0, 0);
+    }
+    const bool live = mb < m_end;
+#pragma unroll
+    for (int i = 0; i < XPIECES; ++i) {
+      const int ih = row0 - 1 + xprow[i];
+      const bool ok = live && xcol[i] >= 0 && ih >= 0 && ih < a.Hi;
+      const unsigned pix = (unsigned)__umul24((unsigned)(img * a.Hs + (ih >> a.ups)), (unsigned)a.Ws) + xcol[i];
+      const unsigned off = ok ? (unsigned)__umul24(pix, (unsigned)csrc2) + xconst[i] : DM_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, DM_LDS(sx + (wave * 64 + NT * i) * 16), 16, off, 0, 0, 0);
+    }
+    row0 += RS;
+    if (row0 >= a.Ho) { row0 = 0; ++img; }
+  };
+
+  // fragment read addresses within a stage
+  const unsigned lds_base = (unsigned)(size_t)DM_LDS(smem);
+  unsigned a_off[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a_off[i] = frag_offset<TCO>(wm * 64 + i * 16, lane) + kg * 32 * TY::ROW_BYTES;
+  // patch fragments: lane's two pixel rows (r0, r0 + 4) of this wave group's 32 pixels, per tap
+  unsigned b_off[3][3][2];
+  {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = kg * 32 + 8 * g + q + 4 * h;
+      const int prow = r / a.Wo, pcol = r - prow * a.Wo;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int pp = (prow + kh) * PW + pcol + kw;
+          const int piece = 2 * wn + (p >> 1);
+          b_off[kh][kw][h] = TY::BYTES + pp * 64 + ((piece ^ half_key(pp, prow + kh)) << 4) + (p & 1) * 8;
+        }
+    }
+  }
+
+  f32x4_t acc[9][MI];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) stage(s);
+  s16x4_t alo[MI], ahi[MI], blo[2][3], bhi[2][3];
+  for (int s = 0; s < nsteps; ++s) {
+    wait_vmcnt<LPS*(NST - 2)>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned sbase = lds_base + (unsigned)((s % NST) * STAGE);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) read_frag<0, 4 * TY::ROW_BYTES>(alo[i], ahi[i], sbase + a_off[i]);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      read_tr(blo[0][kw], sbase + b_off[0][kw][0]);
+      read_tr(bhi[0][kw], sbase + b_off[0][kw][1]);
+    }
+    stage(s + NST - 1);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      read_tr(blo[1][kw], sbase + b_off[1][kw][0]);
+      read_tr(bhi[1][kw], sbase + b_off[1][kw][1]);
+    }
+    wait9<6>(alo, ahi, blo[0], bhi[0]);        // the six reads of kernel row 1 may still be in flight
+    bf16x8_t af[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[i] = join_frag(alo[i], ahi[i]);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const bf16x8_t bfr = join_frag(blo[0][kw], bhi[0][kw]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        acc[kw][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[kw][i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {           // kernel row 2 into the registers kernel row 0 has left
+      read_tr(blo[0][kw], sbase + b_off[2][kw][0]);
+      read_tr(bhi[0][kw], sbase + b_off[2][kw][1]);
+    }
+    wait9<6>(alo, ahi, blo[1], bhi[1]);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const bf16x8_t bfr = join_frag(blo[1][kw], bhi[1][kw]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        acc[3 + kw][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[3 + kw][i], 0, 0, 0);
+    }
+    wait9<0>(alo, ahi, blo[0], bhi[0]);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const bf16x8_t bfr = join_frag(blo[0][kw], bhi[0][kw]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        acc[6 + kw][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[6 + kw][i], 0, 0, 0);
+    }
+  }
+
+  wait_vmcnt<0>();
+  __syncthreads();
+  // ---- epilogue: sum the two wave groups through LDS in accumulator-register order (float4 q = (tap, i) of thread t
+  // at [q][t]) and store the slab with plain stores
+  f32x4_t* ep4 = (f32x4_t*)smem;
+  const int t2 = tid & 255;
+  f32x4_t* slab = (f32x4_t*)a.slabs + (size_t)logical * (SLAB9_FLOATS / 4);
+#pragma unroll
+  for (int t0 = 0; t0 < 9; t0 += EP_TAPS) {
+    if (t0) __syncthreads();   // the first batch has been read
+    if (kg == 1) {
+#pragma unroll
+      for (int t = t0; t < t0 + EP_TAPS && t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) ep4[((t - t0) * MI + i) * 256 + t2] = acc[t][i];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int t = t0; t < t0 + EP_TAPS && t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          slab[(t * MI + i) * 256 + t2] = ep4[((t - t0) * MI + i) * 256 + t2] + acc[t][i];
+    }
+  }
+}
+
+template <int NST>
+__global__ __launch_bounds__(512, 1) void conv_wgrad9_kernel(WgradArgs a) {
+  const int logical = xcd_logical_block();
+  if (logical >= a.n_blocks) return;
+  wgrad9_body<NST>(a, logical);
+}
+
+// Slab sum of the nine-tap kernel (same scheme as wgrad3_reduce_round; float4 q = (tap, i) of thread t2).
+__global__ __launch_bounds__(256) void wgrad9_reduce_kernel(WgradArgs a, int G) {
+  __shared__ f32x4_t red[4][64];
+  constexpr int F4 = SLAB9_FLOATS / 4, CH = F4 / 64;
+  const int per = a.n_co_tiles * a.n_ci_tiles;
+  const int units = per * CH * G;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int u0 = blockIdx.x * 4; u0 < units; u0 += gridDim.x * 4) {
+    const int unit = u0 + wave;
+    const int cid = unit / G, grp = unit - cid * G;
+    const bool live = cid < per * CH;
+    const int inner = live ? cid / CH : 0, chunk = live ? cid - inner * CH : 0;
+    const int e = chunk * 64 + lane;
+    const f32x4_t* src = (const f32x4_t*)a.slabs + (size_t)inner * F4 + e;
+    const size_t stride = (size_t)per * F4;
+    f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      int ks = grp;
+      for (; ks + 3 * G < a.splitk; ks += 4 * G) {
+        const f32x4_t v0 = src[(size_t)ks * stride], v1 = src[(size_t)(ks + G) * stride];
+        const f32x4_t v2 = src[(size_t)(ks + 2 * G) * stride], v3 = src[(size_t)(ks + 3 * G) * stride];
+        sum += v0; sum += v1; sum += v2; sum += v3;
+      }
+      for (; ks < a.splitk; ks += G) sum += src[(size_t)ks * stride];
+    }
+    if (G > 1) {
+      __syncthreads();
+      red[wave][lane] = sum;
+      __syncthreads();
+      if (grp == 0)
+        for (int g = 1; g < G; ++g) sum += red[wave + g][lane];
+    }
+    if (live && grp == 0) {
+      const int q = e >> 8, t2 = e & 255;
+      const int tco = inner / a.n_ci_tiles, tci = inner - tco * a.n_ci_tiles;
+      const int tap = q >> 2, i = q & 3;
+      const int pw = t2 >> 6, l2 = t2 & 63, wm = pw >> 1, wn = pw & 1;
+      const int co = tco * 128 + wm * 64 + i * 16 + (l2 >> 4) * 4;
+      const int ci = tci * 32 + wn * 16 + (l2 & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (co + r < a.Cout) a.dw[((size_t)(co + r) * 9 + tap) * a.Cin + ci] += sum[r];
+    }
+  }
+}
+
 // Several layers in one launch: the weight gradients of a backward pass feed nothing but the optimizer, so a few
 // consecutive layers can wait for each other and share the chip. Every launch leaves one partial tile per workgroup
 // (a CU-full of accumulators, 25 MB) whatever the layer, and rounds its workgroup count up to whole rounds of CUs;
@@ -710,7 +983,7 @@ void make_magic(unsigned d, unsigned& magic, unsigned& shift) {
 
 // The launch plan of a layer: kernel variant, tiles and pixel-axis split.
 struct WgradPlan {
-  bool row3, wide_co, wide_ci;
+  bool row3, row9, wide_co, wide_ci;
   int n_co_tiles, n_ci_tiles, per, splitk, rows_per_split, n_blocks;
   size_t ws_bytes;   // workspace for the partial tiles
 };
@@ -731,18 +1004,27 @@ static int cu_count() {
 }
 
 // tiles of a layer (everything of the plan but the pixel-axis split)
-static WgradPlan plan_tiles(const dm_conv_desc* d) {
+static WgradPlan plan_tiles(const dm_conv_desc* d, bool allow9 = true) {
   WgradPlan p;
   const long M = (long)d->B * d->Ho * d->Wo;
   const int Cin = d->C1 + d->C2;
   p.row3 = g_dm_use_wgrad3 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Wo >= 8 &&
            BKM % d->Wo == 0 && M % BKM == 0 && (BKM / d->Wo) * (d->Wo + 2) <= 128;
+  // all nine taps per workgroup: a step (64 / Wo output rows) inside one image, its patch within 144 pixels
+  // (g_dm_use_wgrad9: 0 off - the default -, 1 layers of >= 512 input channels, 3 also >= 256 channels on images of
+  // >= 16x16, 2 wherever the shape allows. Alone the kernel is 7-19 % faster than the three-tap one from 256 input
+  // channels up and slower below, where its larger partial tiles cost more than the staging saves. Inside a training
+  // step it loses: two waves of 236 VGPRs leave a SIMD 32 registers, so none of the main stream's HBM-bound
+  // GroupNorm waves fit beside it, where the three-tap kernel's 2 x 174 leave 160.)
+  p.row9 = p.row3 && allow9 && g_dm_use_wgrad9 && d->Ho % (BKM / d->Wo) == 0 &&
+           (BKM / d->Wo + 2) * (d->Wo + 2) <= 144 && d->C1 % 32 == 0 && d->C2 % 32 == 0 &&
+           (g_dm_use_wgrad9 == 2 || Cin >= 512 || (g_dm_use_wgrad9 == 3 && Cin >= 256 && M >= 32768));
   p.wide_co = d->Cout % 128 == 0;
   p.wide_ci = d->C1 % 128 == 0 && d->C2 % 128 == 0;
-  const int tco = (p.wide_co || p.row3) ? 128 : 64, tci = (p.wide_ci && !p.row3) ? 128 : 64;
+  const int tco = (p.wide_co || p.row3) ? 128 : 64, tci = p.row9 ? 32 : ((p.wide_ci && !p.row3) ? 128 : 64);
   p.n_co_tiles = dm_cdiv(d->Cout, tco);
   p.n_ci_tiles = Cin / tci;
-  p.per = (p.row3 ? 3 : d->KH * d->KW) * p.n_co_tiles * p.n_ci_tiles;
+  p.per = (p.row9 ? 1 : (p.row3 ? 3 : d->KH * d->KW)) * p.n_co_tiles * p.n_ci_tiles;
   return p;
 }
 
@@ -754,7 +1036,7 @@ static void plan_split(const dm_conv_desc* d, WgradPlan& p, int splitk) {
   p.rows_per_split = dm_cdiv(steps_total, splitk) * BKM;
   p.splitk = dm_cdiv(M, p.rows_per_split);
   p.n_blocks = p.splitk * p.per;
-  p.ws_bytes = (size_t)p.n_blocks * (p.row3 ? SLAB_FLOATS : tco * tci) * sizeof(float);
+  p.ws_bytes = (size_t)p.n_blocks * (p.row9 ? SLAB9_FLOATS : (p.row3 ? SLAB_FLOATS : tco * tci)) * sizeof(float);
 }
 
 static WgradPlan make_plan(const dm_conv_desc* d) {
@@ -784,7 +1066,7 @@ static void make_group_plan(const dm_conv_desc* const* ds, int n, WgradPlan* pla
   const int n_cu = cu_count(), OVERHEAD = g_dm_wgrad_slab_overhead;
   int steps[WG_MAX], max_steps = 1;
   for (int l = 0; l < n; ++l) {
-    plans[l] = plan_tiles(ds[l]);
+    plans[l] = plan_tiles(ds[l], false);
     steps[l] = dm_cdiv((long)ds[l]->B * ds[l]->Ho * ds[l]->Wo, BKM);
     if (steps[l] > max_steps) max_steps = steps[l];
   }
@@ -865,7 +1147,11 @@ static int reduce_waves(int splitk) { return splitk >= 8 ? 4 : (splitk >= 4 ? 2 
 
 static void launch_layer(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   dim3 grid((a.n_blocks + 7) / 8 * 8);
-  if (p.row3) {
+  if (p.row9) {
+    hipLaunchKernelGGL((conv_wgrad9_kernel<4>), grid, dim3(512), 0, st, a);
+    const int G = reduce_waves(a.splitk);
+    hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(reduce_grid((long)p.per * (SLAB9_FLOATS / 256) * G)), dim3(256), 0, st, a, G);
+  } else if (p.row3) {
     hipLaunchKernelGGL((conv_wgrad3_kernel<4>), grid, dim3(512), 0, st, a);
     const int G = reduce_waves(a.splitk);
     hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(reduce_grid((long)p.per * (SLAB_FLOATS / 256) * G)), dim3(256), 0, st, a, G);
@@ -899,7 +1185,7 @@ static int wgrad_group(const dm_wgrad_item* items, int n, char* ws, size_t ws_by
   int i = 0;
   while (i < n) {
     int run = 0;
-    while (i + run < n && run < WG_MAX && plan_tiles(&items[i + run].desc).row3) ++run;
+    while (i + run < n && run < WG_MAX && plan_tiles(&items[i + run].desc, false).row3) ++run;
     if (run <= 1) {   // a layer of another kind, or a three-tap layer with no neighbour to share with
       const dm_wgrad_item& it = items[i];
       const WgradPlan p = make_plan(&it.desc);

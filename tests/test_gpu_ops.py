@@ -59,10 +59,15 @@ CONV_CASES += [
 ]
 
 
-@pytest.mark.parametrize("patch", [1, 0])
+@pytest.mark.parametrize("patch", [1, 2, 0])
 @pytest.mark.parametrize("B,C1,C2,Cout,H,W,k,stride,ups", CONV_CASES)
 def test_conv2d_fwd_bwd(B, C1, C2, Cout, H, W, k, stride, ups, patch):
+    """patch=1: the kernels a training step takes (patch convolution, nine-tap weight gradient where the shape allows);
+    2: the three-tap weight-gradient kernel instead of the nine-tap one; 0: the gathered convolution, the single-tap
+    weight gradient and the stride-2 data gradient over all nine taps."""
     from dm_hip import ops, lib
+    lib.dm_config_set(b"wgrad_row9", 2 if patch == 1 else 0)   # 2: on every shape that qualifies
+    patch = int(patch > 0)
     lib.dm_config_set(b"conv_patch", patch)
     lib.dm_config_set(b"wgrad_row3", patch)   # patch=0 also selects the single-tap weight-gradient kernel
     lib.dm_config_set(b"dgrad_subpixel", patch)   # ... and the stride-2 data gradient over all nine taps
@@ -71,6 +76,7 @@ def test_conv2d_fwd_bwd(B, C1, C2, Cout, H, W, k, stride, ups, patch):
     finally:
         lib.dm_config_set(b"conv_patch", 1)
         lib.dm_config_set(b"wgrad_row3", 1)
+        lib.dm_config_set(b"wgrad_row9", 1)
         lib.dm_config_set(b"dgrad_subpixel", 1)
 
 
