@@ -51,9 +51,17 @@ typedef struct dm_sum_item {
 } dm_sum_item;
 int dm_ordered_sum_group(const dm_sum_item* items, int n_items, void* stream);
 int dm_abi_version(void);
-/* run-time switches: "conv_patch" (default 1): 3x3 stride-1 convs use the LDS-staged-patch kernel;
- * "wgrad_row3" (default 1): their weight gradients use the kernel that shares one staged input row among 3 taps;
- * "gn_fused" (default 1): GroupNorm uses the single-pass (slab in registers) kernels where they apply */
+/* Run-time switches (tuning and A/B measurements; results are the same to the documented tolerances either way):
+ *   "conv_patch" (1)      3x3 stride-1 convolutions use the LDS-staged-patch kernel
+ *   "conv_gn_fuse" (1)    dm_conv2d_gn_fusable may say yes (GroupNorm in the producing convolution's epilogue)
+ *   "dgrad_subpixel" (1)  stride-2 data gradients run by output-pixel parity class
+ *   "wgrad_row3" (1)      3x3 weight gradients share one staged input row among the 3 taps of a kernel row
+ *   "wgrad_row9" (0)      ... or all nine taps per workgroup (1: >= 512 input channels, 3: also >= 256 on images of
+ *                         >= 16x16, 2: wherever the shape allows); faster alone, slower inside a training step
+ *   "wgrad_slab_overhead" (12), "wgrad_reduce_cap" (8192)   split-K planning of the weight-gradient kernels
+ *   "gn_fused" (1), "gn_bwd16" (1)   single-pass GroupNorm kernels; 512 x 16-pixel form of the 1024-pixel backward
+ *   "attn_mfma" (1), "edge_mfma" (1) matrix-core attention (head dims 8, 16) and edge convolutions
+ * Unknown keys fail with DM_ERR_ARG. */
 int dm_config_set(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------------------
