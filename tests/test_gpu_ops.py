@@ -367,6 +367,7 @@ CONV_GN_CASES = [
     (8, 128, 128, 256, 8, 8, 0, True, "ss", True),      # skip concat into the conv, scale/shift mixing
     (5, 64, 0, 64, 16, 16, 0, False, None, True),       # 64-wide tiles, no activation, no embedding
     (4, 128, 0, 128, 8, 8, 1, True, "pre", True),       # through the fused upsampling gather (8x8 -> 16x16)
+    (12, 512, 0, 512, 8, 8, 0, True, "pre", True),      # groups of 16 channels, four per 64-wide tile (the 8x8 stage)
     (2, 64, 0, 64, 32, 32, 0, True, "pre", False),      # a sample spans four tiles: separate launches
     (4, 128, 0, 128, 4, 4, 0, True, "ss", False),       # sixteen samples per tile: more sums than threads
     (2, 64, 0, 192, 16, 16, 0, True, None, False),      # 192 channels: groups of 6 do not tile 64 columns evenly
