@@ -97,6 +97,10 @@ HBM_OPS = {
     "dm_sampler_step": ("sampler_step (DDPM/DDIM/Euler update)", lambda a: (16.0 if a[2] else 12.0) * a[10]),
 }
 CONV_OPS = ("dm_conv2d_igemm", "dm_conv2d_igemm_gn", "dm_conv2d_wgrad", "dm_conv2d_wgrad_group")
+# Kernels of a few microseconds: an event bracket around ONE eager call times the host's launch path, not the kernel.
+# These are timed as BURST launches of the same call replayed from a HIP graph (idempotent or throw-away outputs).
+BURST_OPS = ("dm_diffuse", "dm_mse_loss_fwd", "dm_mse_loss_bwd", "dm_sampler_step", "dm_grad_norm")
+BURST = 20
 
 
 class AbiTimer:
@@ -145,9 +149,34 @@ class AbiTimer:
             e0.record()
             rc = fn(*args)
             e1.record()
-            self.records.append((name, work, e0, e1, nbytes, shape))
+            ms = self._burst_ms(fn, args) if name in BURST_OPS else None
+            self.records.append((name, work, e0, e1, nbytes, shape, ms))
             return rc
         return call
+
+    @staticmethod
+    def _burst_ms(fn, args):
+        """Average duration of one launch of fn(*args) (its last argument is the stream) inside a graph of BURST of
+        them, replayed once warm; None if the capture fails (the single-call bracket is used then)."""
+        try:
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(st):
+                with torch.cuda.graph(g, stream=st):
+                    for _ in range(BURST):
+                        fn(*args[:-1], st.cuda_stream)
+                g.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g.replay()
+                e1.record()
+            torch.cuda.current_stream().wait_stream(st)
+            e1.synchronize()
+            return e0.elapsed_time(e1) / BURST
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"[bench] burst timing failed ({e!r}); single-call bracket used\n")
+            return None
 
     def __exit__(self, *exc):
         for name, fn in self._orig.items():
@@ -157,8 +186,8 @@ class AbiTimer:
         torch.cuda.synchronize()
         out = {}
         dump = os.environ.get("DM_BENCH_DUMP_CONVS")
-        for name, flops, e0, e1, nbytes, shape in self.records:
-            ms = e0.elapsed_time(e1)
+        for name, flops, e0, e1, nbytes, shape, burst_ms in self.records:
+            ms = burst_ms if burst_ms is not None else e0.elapsed_time(e1)
             if dump and shape and shape[0] == "gn":
                 sys.stderr.write(f"[gn] {shape[1]} B={shape[2]} HW={shape[3]:5d} C={shape[4]}+{shape[5]} extra={int(shape[6])} "
                                  f"{nbytes / 1e6:7.1f} MB {ms * 1e3:7.1f} us {nbytes / ms / 1e9:6.2f} TB/s\n")
@@ -339,8 +368,8 @@ def emit(line: dict):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cos_cifar")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's batch_size)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a HIP graph")
@@ -367,15 +396,21 @@ def main():
                     help="streams the weight-gradient kernels rotate over beside the main one (0: none; default: the harness's)")
     args = ap.parse_args()
 
-    if os.environ.get("DM_BENCH_WATCHDOG"):    # a stuck rank says where: Python stacks to stderr every N seconds
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["DM_BENCH_WATCHDOG"]), repeat=True)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    # A rank that is stuck (a collective nobody joins, a hung launch) says where and ENDS: Python stacks of every thread
+    # to stderr and exit status 1 after DM_BENCH_WATCHDOG seconds (default: 15 minutes on more than one GPU, where the
+    # launcher then takes the other ranks down; off on one GPU unless set). The whole default run takes 2-3 minutes.
+    watchdog = int(os.environ.get("DM_BENCH_WATCHDOG", "900" if world > 1 else "0"))
+    if watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(watchdog, exit=True)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.force_collectives:
         args.split_graph = True
+    if os.environ.get("DM_BENCH_SHARE_GPU") == "1":
+        local_rank = 0      # rehearsal on a one-GPU box: every rank on the one device (with DM_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # Everything runs on a stream of the benchmark's own, not the legacy default stream: that one synchronises
@@ -391,7 +426,11 @@ def main():
         os.dup2(2, 1)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        import datetime
+        # (a collective that does not complete within five minutes is aborted by the process group's own watchdog,
+        # which ends the process with an error)
+        dist.init_process_group(os.environ.get("DM_BENCH_BACKEND", "nccl"), device_id=device,
+                                timeout=datetime.timedelta(minutes=5))
     elif args.force_collectives:
         # a process group of one rank over RCCL: every collective of the multi-GPU path really runs (one-GPU rehearsal)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -12,7 +12,7 @@ void dm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dm_last_error(void) { return g_err; }
-extern "C" int dm_abi_version(void) { return 2; }
+extern "C" int dm_abi_version(void) { return 3; }
 
 // run-time switches (tests exercise both convolution paths)
 int g_dm_use_patch_kernel = 1;
@@ -27,18 +27,42 @@ int g_dm_edge_mfma = 1;               // UNet edge convs (image <-> features): m
 int g_dm_attn_mfma = 1;              // head dims 8 / 16: attention core on the matrix cores
 int g_dm_gn_bwd16 = 1;               // 513..1024-pixel GroupNorm backward: 512 threads x 16 pixels (no spills) instead of 1024 x 8
 
+namespace {
+struct Switch { const char* key; int* value; int initial; };
+// every switch with the value the library starts with (dm_config_reset restores these)
+const Switch kSwitches[] = {
+  {"conv_patch", &g_dm_use_patch_kernel, 1},     {"wgrad_row3", &g_dm_use_wgrad3, 1},
+  {"wgrad_slab_overhead", &g_dm_wgrad_slab_overhead, 12}, {"wgrad_reduce_cap", &g_dm_wgrad_reduce_cap, 8192},
+  {"gn_fused", &g_dm_gn_fused, 1},               {"conv_gn_fuse", &g_dm_conv_gn_fuse, 1},
+  {"wgrad_row9", &g_dm_use_wgrad9, 0},           {"dgrad_subpixel", &g_dm_dgrad_subpixel, 1},
+  {"edge_mfma", &g_dm_edge_mfma, 1},             {"attn_mfma", &g_dm_attn_mfma, 1},
+  {"gn_bwd16", &g_dm_gn_bwd16, 1},
+};
+const Switch* find_switch(const char* key) {
+  if (key)
+    for (const Switch& s : kSwitches)
+      if (!strcmp(key, s.key)) return &s;
+  dm_set_error("dm_config: unknown key '%s'", key ? key : "(null)");
+  return nullptr;
+}
+}  // namespace
+
 extern "C" int dm_config_set(const char* key, int value) {
-  if (key && !strcmp(key, "conv_patch")) { g_dm_use_patch_kernel = value; return DM_OK; }
-  if (key && !strcmp(key, "wgrad_row3")) { g_dm_use_wgrad3 = value; return DM_OK; }
-  if (key && !strcmp(key, "wgrad_slab_overhead")) { g_dm_wgrad_slab_overhead = value; return DM_OK; }
-  if (key && !strcmp(key, "wgrad_reduce_cap")) { g_dm_wgrad_reduce_cap = value > 0 ? value : 1; return DM_OK; }
-  if (key && !strcmp(key, "gn_fused")) { g_dm_gn_fused = value; return DM_OK; }
-  if (key && !strcmp(key, "conv_gn_fuse")) { g_dm_conv_gn_fuse = value; return DM_OK; }
-  if (key && !strcmp(key, "wgrad_row9")) { g_dm_use_wgrad9 = value; return DM_OK; }
-  if (key && !strcmp(key, "dgrad_subpixel")) { g_dm_dgrad_subpixel = value; return DM_OK; }
-  if (key && !strcmp(key, "edge_mfma")) { g_dm_edge_mfma = value; return DM_OK; }
-  if (key && !strcmp(key, "attn_mfma")) { g_dm_attn_mfma = value; return DM_OK; }
-  if (key && !strcmp(key, "gn_bwd16")) { g_dm_gn_bwd16 = value; return DM_OK; }
-  dm_set_error("dm_config_set: unknown key '%s'", key ? key : "(null)");
-  return DM_ERR_ARG;
+  const Switch* s = find_switch(key);
+  if (!s) return DM_ERR_ARG;
+  if (s->value == &g_dm_wgrad_reduce_cap && value < 1) value = 1;
+  *s->value = value;
+  return DM_OK;
+}
+
+extern "C" int dm_config_get(const char* key, int* value) {
+  const Switch* s = find_switch(key);
+  if (!s) return DM_ERR_ARG;
+  DM_REQUIRE(value, DM_ERR_ARG, "dm_config_get: null output");
+  *value = *s->value;
+  return DM_OK;
+}
+
+extern "C" void dm_config_reset(void) {
+  for (const Switch& s : kSwitches) *s.value = s.initial;
 }

@@ -24,7 +24,8 @@ __global__ __launch_bounds__(NT) void sumsq_partial_kernel(const float* __restri
   if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(NT) void norm_final_kernel(const float* __restrict__ partials, int np, float* __restrict__ out) {
+__global__ __launch_bounds__(NT) void norm_final_kernel(const float* __restrict__ partials, int np, float grad_scale,
+                                                       float* __restrict__ out) {
   __shared__ double red[NT];
   double s = 0.0;
   for (int i = threadIdx.x; i < np; i += NT) s += (double)partials[i];
@@ -34,14 +35,15 @@ __global__ __launch_bounds__(NT) void norm_final_kernel(const float* __restrict_
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = (float)sqrt(red[0]);
+  if (threadIdx.x == 0) out[0] = fabsf(grad_scale) * (float)sqrt(red[0]);
 }
 
-__global__ __launch_bounds__(NT) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+template <bool ZERO>
+__global__ __launch_bounds__(NT) void adamw_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, float* __restrict__ ema, bf16_t* __restrict__ wb,
                                                        const float* __restrict__ norm, float max_norm, long n, float lr,
                                                        float b1, float b2, float eps, float wd, float bc1, float bc2,
-                                                       float ema_decay, const float* __restrict__ hyper) {
+                                                       float ema_decay, const float* __restrict__ hyper, float grad_scale) {
   if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; ema_decay = hyper[3]; }
   float clip = 1.f;
   if (max_norm > 0.f && norm) {
@@ -52,7 +54,8 @@ __global__ __launch_bounds__(NT) void adamw_ema_kernel(float* __restrict__ p, co
   const float sqrt_bc2 = sqrtf(bc2);
   const float omd = 1.f - ema_decay;
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
-    const float gi = g[i] * clip;
+    const float gi = g[i] * grad_scale * clip;
+    if (ZERO) g[i] = 0.f;
     float pi = p[i] * (1.f - lr * wd);
     const float mi = m[i] + (1.f - b1) * (gi - m[i]);
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -97,27 +100,32 @@ extern "C" int dm_optimizer_tick(long long* step, float* hyper, float lr, float 
 
 extern "C" int dm_sumsq_partials(void) { return NPART; }
 
-extern "C" int dm_grad_norm(const float* g, long n, float* partials, float* norm_out, void* stream) {
+extern "C" int dm_grad_norm(const float* g, long n, float grad_scale, float* partials, float* norm_out, void* stream) {
   DM_REQUIRE(g && partials && norm_out && n > 0, DM_ERR_ARG, "dm_grad_norm: bad argument");
   DM_REQUIRE((uintptr_t)g % 16 == 0, DM_ERR_ARG, "dm_grad_norm: gradient arena must be 16-byte aligned");
   long gl = ((n >> 2) + NT - 1) / NT;
   int grid = (int)(gl > NPART ? NPART : (gl < 1 ? 1 : gl));
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, g, n, partials);
   DM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, partials, grid, norm_out);
+  hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, partials, grid, grad_scale, norm_out);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }
 
-extern "C" int dm_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* w_bf16, const float* norm,
+extern "C" int dm_adamw_ema_step(float* p, float* g, float* m, float* v, float* ema, void* w_bf16, const float* norm,
                                  float max_norm, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
-                                 float bc2, float ema_decay, const float* hyper, void* stream) {
+                                 float bc2, float ema_decay, const float* hyper, float grad_scale, int zero_grad,
+                                 void* stream) {
   DM_REQUIRE(p && g && m && v && n > 0, DM_ERR_ARG, "dm_adamw_ema_step: bad argument");
   DM_REQUIRE(!(max_norm > 0.f) || norm, DM_ERR_ARG, "dm_adamw_ema_step: clipping needs the norm");
   long gl = (n + NT - 1) / NT;
   int grid = (int)(gl > 4096 ? 4096 : gl);
-  hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16_t*)w_bf16, norm,
-                     max_norm, n, lr, b1, b2, eps, wd, bc1, bc2, ema_decay, hyper);
+  if (zero_grad)
+    hipLaunchKernelGGL(adamw_ema_kernel<true>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16_t*)w_bf16,
+                       norm, max_norm, n, lr, b1, b2, eps, wd, bc1, bc2, ema_decay, hyper, grad_scale);
+  else
+    hipLaunchKernelGGL(adamw_ema_kernel<false>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16_t*)w_bf16,
+                       norm, max_norm, n, lr, b1, b2, eps, wd, bc1, bc2, ema_decay, hyper, grad_scale);
   DM_CHECK_LAUNCH();
   return DM_OK;
 }

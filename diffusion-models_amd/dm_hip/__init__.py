@@ -55,6 +55,8 @@ P = c_void_p
 _SIGNATURES = {
     "dm_abi_version": (c_int, []),
     "dm_config_set": (c_int, [ctypes.c_char_p, c_int]),
+    "dm_config_get": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int)]),
+    "dm_config_reset": (None, []),
     "dm_conv2d_igemm": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "dm_conv2d_gn_fusable": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(GnDesc)]),
     "dm_conv2d_igemm_gn": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, ctypes.POINTER(GnDesc)] + [P] * 8),
@@ -106,8 +108,8 @@ _SIGNATURES = {
     "dm_nn2_ws_floats": (c_long, [c_int, c_int]),
     "dm_nn2_distances": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P]),
     "dm_sumsq_partials": (c_int, []),
-    "dm_grad_norm": (c_int, [P, c_long, P, P, P]),
-    "dm_adamw_ema_step": (c_int, [P, P, P, P, P, P, P, c_float, c_long] + [c_float] * 8 + [P, P]),
+    "dm_grad_norm": (c_int, [P, c_long, c_float, P, P, P]),
+    "dm_adamw_ema_step": (c_int, [P, P, P, P, P, P, P, c_float, c_long] + [c_float] * 8 + [P, c_float, c_int, P]),
     "dm_optimizer_tick": (c_int, [P, P] + [c_float] * 6 + [P]),
 }
 
@@ -131,8 +133,14 @@ def check(rc):
         raise DmHipError(f"libdm_hip status {rc}: {lib.dm_last_error().decode()}")
 
 
-# DM_HIP_CONFIG="key=value,key=value": run-time switches of the library (dm_config_set) from the environment, for
-# tuning runs; unknown keys are errors.
-for _kv in filter(None, os.environ.get("DM_HIP_CONFIG", "").split(",")):
-    _k, _, _v = _kv.partition("=")
-    check(lib.dm_config_set(_k.strip().encode(), int(_v)))
+def reset_config():
+    """Every run-time switch of the library back to its built-in value, then DM_HIP_CONFIG="key=value,key=value" from
+    the environment applied on top (tuning runs; unknown keys are errors). Runs at import; tests call it after
+    every case so that no case leaves a switch behind for the next."""
+    lib.dm_config_reset()
+    for kv in filter(None, os.environ.get("DM_HIP_CONFIG", "").split(",")):
+        k, _, v = kv.partition("=")
+        check(lib.dm_config_set(k.strip().encode(), int(v)))
+
+
+reset_config()

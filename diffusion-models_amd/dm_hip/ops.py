@@ -185,9 +185,14 @@ def aux_streams():
     return list(_AUX.values())
 
 
+LAUNCHES = 0     # operator launches so far (every call takes its stream from _stream / _param_stream)
+
+
 def _stream():
     """Raw handle of the current stream (what the kernels launch on); work on an auxiliary stream marks it as one
     that the consumer of the gradients has to wait for."""
+    global LAUNCHES
+    LAUNCHES += 1
     raw = torch.cuda.current_stream().cuda_stream
     if _AUX:
         s = _AUX.get(raw)
@@ -270,7 +275,8 @@ def _param_stream(tensors, enable=True):
     it), else the current stream."""
     if not (SIDE_WGRAD and enable):
         return _stream(), None
-    global _SIDE_NEXT
+    global _SIDE_NEXT, LAUNCHES
+    LAUNCHES += 1
     side = side_stream(tensors[0].device, _SIDE_NEXT % SIDE_WGRAD)
     _SIDE_NEXT += 1
     side.wait_stream(torch.cuda.current_stream())

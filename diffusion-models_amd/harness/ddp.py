@@ -9,8 +9,10 @@ CPU tensors, which is how the multi-process tests exercise it.
 """
 from typing import List, Sequence, Tuple
 
+import datetime
 import os
 import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -18,7 +20,9 @@ import torch.distributed as dist
 
 def cut_buckets(offsets: Sequence[int], total: int, bucket_elems: int) -> List[Tuple[int, int]]:
     """[lo, hi) element ranges covering [0, total), boundaries on parameter offsets, each >= bucket_elems
-    (except possibly the one that ends at parameter 0), listed from the END of the arena to its start."""
+    (except possibly the one that starts at element 0), listed from the END of the arena to its start. `offsets` may
+    come in any order (a parameter's index need not follow its position in the arena)."""
+    offsets = sorted(offsets)
     buckets, hi = [], total
     for i in range(len(offsets) - 1, -1, -1):
         lo = offsets[i]
@@ -55,12 +59,19 @@ class BucketedAllReduce:
         # current one (every stream parameter-gradient kernels run on); None: the current stream only.
         self.extra_streams = None
         self.early = 0   # buckets launched before finish() in the last step (i.e. while backward was running)
+        # A collective that has not completed this many seconds after finish() started waiting for it is reported
+        # (rank, bucket, state of every stream) and raised as an error, so that a stuck rank ends its process with a
+        # non-zero status instead of waiting for ever. Applies where waiting blocks the host (gloo) and, with
+        # DM_DDP_DEBUG set, to every backend (RCCL's own watchdog covers the device-side wait otherwise).
+        self.timeout_s = float(os.environ.get("DM_DDP_TIMEOUT", "120"))
+        self.order = []  # bucket indices in the order their collectives were issued in the last step
         self.begin()
 
     def begin(self):
         """Call before backward."""
         self.ready, self.launched, self.handles = set(), set(), []
         self.count = [0] * len(self.buckets)
+        self.order = []
 
     def on_ready(self, param_index: int):
         """Parameter `param_index`'s gradient has been enqueued. Launches its bucket when the bucket is complete."""
@@ -89,8 +100,14 @@ class BucketedAllReduce:
     def _launch(self, b, plain=False):
         lo, hi = self.buckets[b]
         self.launched.add(b)
+        self.order.append(b)
         if not self.have_group:
             return
+        if _debug():
+            cur = torch.cuda.current_stream() if self.grad.is_cuda else None
+            _say(self, f"issue #{len(self.handles)} bucket {b} [{lo}, {hi}) from stream "
+                       f"{cur.cuda_stream if cur is not None else '-'}"
+                       f"{' via side streams' if (self.extra_streams is not None and not plain) else ''}")
         sides = list(self.extra_streams()) if (self.extra_streams is not None and not plain) else []
         if sides:
             # issue from the first side stream after making it wait for the main one and for the other side streams:
@@ -107,19 +124,57 @@ class BucketedAllReduce:
         self.handles.append(h)
 
     def finish(self, plain=False):
-        """Call after backward: reduces buckets whose parameters never all reported (unused parameters), waits,
-        and turns the sums into means."""
+        """Call after backward: reduces buckets whose parameters never all reported (unused parameters) and makes
+        the current stream wait for every collective. The arena then holds the SUM of the ranks' gradients."""
         if not self.active:
             return
         self.early = len(self.launched)
         for b in range(len(self.buckets)):
             if b not in self.launched:
                 self._launch(b, plain)
-        debug = os.environ.get("DM_DDP_DEBUG") == "1"
         for i, h in enumerate(self.handles):
-            if debug:
-                sys.stderr.write(f"[ddp rank {dist.get_rank(self.group) if self.have_group else 0}] wait {i}/{len(self.handles)}\n")
-            h.wait()
+            self._wait(i, h)
         self.handles = []
-        if self.world > 1:
-            self.grad.mul_(1.0 / self.world)
+        # (the arena now holds the SUM over ranks; the optimizer kernels apply 1 / world on the fly)
+
+    def _wait(self, i, h):
+        """Make the current stream (and, where the backend blocks, the host) wait for collective number i."""
+        blocking = self.have_group and dist.get_backend(self.group) != "nccl"
+        if not (blocking or _debug()):
+            h.wait()    # RCCL: a device-side wait enqueued on the current stream, returns at once
+            return
+        t0, told = time.monotonic(), 0.0
+        while not h.is_completed():
+            waited = time.monotonic() - t0
+            if waited > self.timeout_s:
+                _say(self, f"collective #{i} (bucket {self.order[i] if i < len(self.order) else '?'}) not complete after "
+                           f"{waited:.0f} s; issue order {self.order}; {self._stream_state()}", force=True)
+                raise RuntimeError(f"data-parallel all-reduce #{i} did not complete within {self.timeout_s:.0f} s")
+            if _debug() and waited - told > 5.0:
+                told = waited
+                _say(self, f"waiting for #{i} since {waited:.0f} s; {self._stream_state()}")
+            time.sleep(0.0005)
+        h.wait()
+        if _debug():
+            _say(self, f"done #{i} (bucket {self.order[i] if i < len(self.order) else '?'})")
+
+    def _stream_state(self):
+        """Which of the streams involved still hold unfinished work (debug output of a stuck wait)."""
+        if not self.grad.is_cuda:
+            return "cpu tensors"
+        streams = {"current": torch.cuda.current_stream()}
+        if self.extra_streams is not None:
+            for k, s_ in enumerate(self.extra_streams()):
+                streams[f"side{k}"] = s_
+        return "streams " + ", ".join(f"{k}:{'idle' if s_.query() else 'busy'}" for k, s_ in streams.items())
+
+
+def _debug():
+    return os.environ.get("DM_DDP_DEBUG", "0") not in ("", "0")
+
+
+def _say(red, text, force=False):
+    if force or _debug():
+        rank = dist.get_rank(red.group) if red.have_group else 0
+        sys.stderr.write(f"[ddp rank {rank} t={time.monotonic():.3f}] {text}\n")
+        sys.stderr.flush()

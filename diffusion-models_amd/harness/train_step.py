@@ -31,17 +31,35 @@ from modeling.layers import Conv2d
 _ALIGN = 64  # floats: every parameter starts on a 256-byte boundary
 
 
+def arena_layout(names, numels, late=()):
+    """Element offset of every parameter in the flat arenas, and their total size. `names` / `numels` are in
+    registration order and so is the returned list (offsets[i] belongs to parameter i), but the PHYSICAL order differs in
+    one respect: the parameters listed in `late` come first, in front of parameter 0. The data-parallel reducer cuts
+    the arena into buckets from its end to its start - the order in which backward produces gradients - so the front
+    of the arena is the bucket that leaves last. `late` names the parameters whose gradients exist only when backward
+    is over wherever they are registered (the embedding path of the UNet: one grouped launch behind the last block's
+    backward produces the gradients of every block's emb_proj). Left in registration order they would sit in every
+    bucket and hold every all-reduce back to the end of backward."""
+    late = set(late)
+    order = [i for i, n in enumerate(names) if n in late] + [i for i, n in enumerate(names) if n not in late]
+    offsets, off = [0] * len(names), 0
+    for i in order:
+        offsets[i] = off
+        off += (numels[i] + _ALIGN - 1) // _ALIGN * _ALIGN
+    return offsets, off
+
+
 class FlatArena:
-    """Parameters of a module re-homed into one contiguous fp32 buffer, in registration order."""
+    """Parameters of a module re-homed into one contiguous fp32 buffer. self.params / names / shapes / offsets are in
+    registration order (the order of state_dict() and of the optimizer state); the physical order is arena_layout's."""
 
     def __init__(self, module: torch.nn.Module):
         self.params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         device = self.params[0][1].device
         conv_weights = {id(m.weight) for m in module.modules() if isinstance(m, Conv2d)}
-        self.offsets, off = [], 0
-        for _, p in self.params:
-            self.offsets.append(off)
-            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        late_fn = getattr(module, "late_gradient_parameter_names", None)
+        self.late = set(late_fn()) if late_fn is not None else set()
+        self.offsets, off = arena_layout([n for n, _ in self.params], [p.numel() for _, p in self.params], self.late)
         self.numel = off
         self.data = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
@@ -264,6 +282,11 @@ class TrainStep:
         current graph behind everything that produced the bucket and open the next one. At replay the bucket's
         all-reduce is issued between the two graphs and runs beside the rest of backward."""
         seg = self._seg
+        if len(self.reducer.launched) == len(self.reducer.buckets):
+            return   # the last bucket: nothing of backward is left to run beside it, its collective follows the chain
+        seg["cut"].add(b)
+        seg["launches"].append(ops.LAUNCHES - seg["mark"])
+        seg["mark"] = ops.LAUNCHES
         # on the capture's own stream: the report may come from an operator running on an auxiliary stream
         with torch.cuda.stream(seg["stream"]):
             joined = self._join_sides()
@@ -293,7 +316,8 @@ class TrainStep:
         stream = stream or torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.synchronize()
-        seg = self._seg = {"graphs": [], "after": [], "pool": torch.cuda.graph_pool_handle(), "stream": stream}
+        seg = self._seg = {"graphs": [], "after": [], "pool": torch.cuda.graph_pool_handle(), "stream": stream,
+                           "cut": set(), "launches": [], "mark": ops.LAUNCHES}
         with torch.cuda.stream(stream):
             # (relaxed mode: autograd runs backward on its own thread, so a capture begun on this one is ended
             # on that one at the first cut, and the last one the other way round)
@@ -313,11 +337,13 @@ class TrainStep:
             finally:
                 self._seg = None
                 seg["graphs"][-1].capture_end()
-            seg["after"].append([b for b in range(len(self.reducer.buckets)) if b not in self.reducer.launched])
+            seg["after"].append([b for b in range(len(self.reducer.buckets)) if b not in seg["cut"]])
+            seg["launches"].append(ops.LAUNCHES - seg["mark"])
         torch.cuda.current_stream().wait_stream(stream)
         self.segments = (seg["graphs"], seg["after"])
-        if os.environ.get("DM_DDP_DEBUG") == "1":
-            sys.stderr.write(f"[segments] {seg['after']}\n")
+        self.segment_launches = seg["launches"]    # operator launches captured into each graph of the chain
+        if os.environ.get("DM_DDP_DEBUG", "0") not in ("", "0"):
+            sys.stderr.write(f"[segments] buckets after each graph {seg['after']}, launches per graph {seg['launches']}\n")
         return loss
 
     def replay_segmented(self):
@@ -336,7 +362,7 @@ class TrainStep:
             own.wait_stream(cur)
         with torch.cuda.stream(own) if own is not None else contextlib.nullcontext():
             self.reducer.begin()
-            debug = os.environ.get("DM_DDP_DEBUG") == "2"
+            debug = os.environ.get("DM_DDP_DEBUG") == "2"   # (serialises: every graph is waited for before the next)
             for i, (g, buckets) in enumerate(zip(graphs, after)):
                 g.replay()
                 if debug:
@@ -356,8 +382,10 @@ class TrainStep:
         """Clip, AdamW, EMA, bf16 weight mirrors, zero the gradients (train.py:441-450)."""
         a = self.arena
         st = torch.cuda.current_stream().cuda_stream
+        # the arena holds the SUM of the ranks' gradients: the mean is taken on the fly by both kernels
+        gscale = 1.0 / self.world if self.reducer.active and self.reducer.have_group else 1.0
         if self.clip > 0:
-            check(lib.dm_grad_norm(a.grad.data_ptr(), a.numel, self.partials.data_ptr(), self.norm.data_ptr(), st))
+            check(lib.dm_grad_norm(a.grad.data_ptr(), a.numel, gscale, self.partials.data_ptr(), self.norm.data_ptr(), st))
         ig, pw, mx = self.ema_cfg
         check(lib.dm_optimizer_tick(self.step_dev.data_ptr(), self.hyper.data_ptr(), self.lr, self.betas[0],
                                     self.betas[1], ig, pw, mx, st))
@@ -365,9 +393,8 @@ class TrainStep:
                                     self.ema.data_ptr() if self.ema is not None else None, self.w16.data_ptr(),
                                     self.norm.data_ptr() if self.clip > 0 else None, self.clip, a.numel, self.lr,
                                     self.betas[0], self.betas[1], self.eps, self.wd, 1.0, 1.0, 0.0,
-                                    self.hyper.data_ptr(), st))
+                                    self.hyper.data_ptr(), gscale, 1, st))   # (zeroes the gradients behind its read)
         self._transpose_mirror()
-        a.grad.zero_()
         self.steps += 1
         ops.WEIGHTS_EPOCH += 1  # packed bf16 copies of the weights are stale now
 

@@ -142,5 +142,18 @@ class UNet(nn.Module, GuidedPredictor):
         # every ConvBlock projects the same SiLU(embedding): do all projections in one grouped launch
         return ProjectedEmbeddings(embedding, self._conv_blocks)
 
+    def late_gradient_parameter_names(self):
+        """Names of the parameters whose gradients appear only when backward is over, wherever they are registered:
+        the embedding path. Every block's emb_proj is computed (and differentiated) in one grouped launch, which can
+        run only after the LAST block of backward has produced its share, followed by the time MLP and the class
+        table. A harness that ships gradients bucket by bucket during backward keeps these out of the early buckets."""
+        late = [n for n, _ in self.time_embedding.named_parameters(prefix="time_embedding")]
+        if self.class_embedding is not None:
+            late.append("class_embedding.weight")
+        for n, m in self.named_modules():
+            if isinstance(m, ConvBlock) and m.emb_proj is not None:
+                late += [f"{n}.emb_proj.{k}" for k, _ in m.emb_proj.named_parameters()]
+        return late
+
     def pred_conditional(self, z, t, cond=None, uncond_mask=None):
         return self.forward(z, t, cls=cond, uncond_mask=uncond_mask)

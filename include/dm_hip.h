@@ -63,6 +63,9 @@ int dm_abi_version(void);
  *   "attn_mfma" (1), "edge_mfma" (1) matrix-core attention (head dims 8, 16) and edge convolutions
  * Unknown keys fail with DM_ERR_ARG. */
 int dm_config_set(const char* key, int value);
+int dm_config_get(const char* key, int* value);
+/* every switch back to the value in brackets above (the configuration the library starts with) */
+void dm_config_reset(void);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on bf16 MFMA.
@@ -337,14 +340,18 @@ int dm_cfg_combine(const float* pred_uncond, const float* pred_cond, float* out,
  * Optimizer tail on flat fp32 arenas (train.py:441-450: clip_grad_norm_, AdamW.step, EMAModel.step).
  */
 int dm_sumsq_partials(void);
-/* norm_out[0] = sqrt(sum g^2); partials: fp32 scratch of dm_sumsq_partials() elements */
-int dm_grad_norm(const float* g, long n, float* partials, float* norm_out, void* stream);
-/* clip = min(1, max_norm / (norm[0] + 1e-6)) applied to g on the fly (max_norm <= 0: no clipping);
+/* norm_out[0] = |grad_scale| * sqrt(sum g^2): the global L2 norm of grad_scale * g (clip_grad_norm_'s norm,
+ * train.py:441-444). grad_scale is 1 on one GPU and 1 / world size when g holds the SUM of the ranks' gradients (the
+ * data-parallel mean is then never written to memory). partials: fp32 scratch of dm_sumsq_partials() elements */
+int dm_grad_norm(const float* g, long n, float grad_scale, float* partials, float* norm_out, void* stream);
+/* The gradient used is grad_scale * g, with clip = min(1, max_norm / (norm[0] + 1e-6)) applied on the fly (max_norm <= 0:
+ * no clipping; norm as dm_grad_norm produced it with the same grad_scale);
  * AdamW with decoupled weight decay and bias corrections bc1 = 1 - b1^step, bc2 = 1 - b2^step; then
- * ema -= (1 - ema_decay) * (ema - p) when ema != null; w_bf16 (nullable) receives the bf16 copy of p */
-int dm_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* w_bf16, const float* norm,
+ * ema -= (1 - ema_decay) * (ema - p) when ema != null; w_bf16 (nullable) receives the bf16 copy of p.
+ * zero_grad != 0: g is zeroed behind the read (optimizer.zero_grad of train.py:448 without a pass of its own). */
+int dm_adamw_ema_step(float* p, float* g, float* m, float* v, float* ema, void* w_bf16, const float* norm,
                       float max_norm, long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
-                      float ema_decay, const float* hyper, void* stream);
+                      float ema_decay, const float* hyper, float grad_scale, int zero_grad, void* stream);
 /* Device-side step bookkeeping for graph replay: step[0] += 1; hyper = {lr, 1 - b1^step, 1 - b2^step, ema_decay}
  * with the warm-up EMA rule decay = min(1 - (1 + (step-1)/inv_gamma)^-power, max_decay) (0 on the first step).
  * When `hyper` (device, 4 floats) is passed to dm_adamw_ema_step it overrides lr, bc1, bc2 and ema_decay. */

@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _library_switches_restored():
+    """Whatever dm_config_set switches a test flips, the next test starts from the library's own configuration - the
+    one bench.py times - so that the model-level tests exercise the kernels that ship as the default."""
+    yield
+    try:
+        import dm_hip
+    except ImportError:
+        return
+    dm_hip.reset_config()
+
+
 # Collection order: oracle and host logic, then operator parity, layer/model/sampler/training parity against the
 # reference fixtures, and only then the harness's self-consistency and multi-process tests - under `pytest -x` a
 # failure in a late file cannot hide the parity tests. Unlisted files run after the listed ones, by name.

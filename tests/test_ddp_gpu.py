@@ -67,7 +67,13 @@ def _worker(rank, world, port, q, side_wgrad=1, segmented=False):
             gnorm = step.norm.clone()
             early = sum(len(bs) for bs in step.segments[1][:-1])
             assert world == 1 or len(step.segments[0]) > 2
+            # no graph of the chain is empty, and every bucket but the last has one behind which its collective goes out
+            assert all(n > 0 for n in step.segment_launches), step.segment_launches
+            assert world == 1 or [len(bs) for bs in step.segments[1][:-1]] == [1] * (len(step.reducer.buckets) - 1)
         torch.cuda.synchronize()
+        if world > 1:    # all but the last bucket (which holds the embedding path and the first layers) left early
+            assert early >= len(step.reducer.buckets) - 2, (early, len(step.reducer.buckets))
+            assert segmented == "phases" or step.reducer.order == list(range(len(step.reducer.buckets))), step.reducer.order
         q.put((rank, float(loss), float(gnorm), (step.arena.data - before).cpu().numpy(), early))
     finally:
         if world > 1:
@@ -108,7 +114,7 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(side_wgrad):
     assert abs(0.5 * (two[0][1] + two[1][1]) - loss1) < 1e-3 * abs(loss1)
     for _, _, norm2, delta2, early in two:
         assert abs(norm2 - norm1) < 5e-3 * norm1          # global norm of the AVERAGED gradient, on every rank
-        assert early > 0                                   # buckets went out before backward had finished
+        assert early > 0                                   # buckets went out before backward had finished (the worker checks how many)
         num = float((delta2 - delta1).norm()) / float(delta1.norm())
         assert num < 0.1, num                              # same AdamW update (bf16 kernels, other batch split: not bit-equal)
     assert torch.equal(two[0][3], two[1][3])               # replicas stay identical

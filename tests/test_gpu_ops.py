@@ -76,7 +76,7 @@ def test_conv2d_fwd_bwd(B, C1, C2, Cout, H, W, k, stride, ups, patch):
     finally:
         lib.dm_config_set(b"conv_patch", 1)
         lib.dm_config_set(b"wgrad_row3", 1)
-        lib.dm_config_set(b"wgrad_row9", 1)
+        lib.dm_config_set(b"wgrad_row9", 0)
         lib.dm_config_set(b"dgrad_subpixel", 1)
 
 
@@ -740,12 +740,16 @@ def test_adamw_ema_step_matches_torch():
         opt.step()
         decay = 0.0 if step == 1 else min(1 - (1 + (step - 1)) ** -0.75, 0.9999)
         ema_ref.sub_((1 - decay) * (ema_ref - ref.detach()))
-        gd = gs.to(d)
-        check(lib.dm_grad_norm(gd.data_ptr(), n, partials.data_ptr(), norm.data_ptr(), st))
+        # the buffer holds the SUM over `world` ranks, grad_scale = 1 / world turns it into the mean on the fly
+        # (powers of two: exact); on the last step the kernel also zeroes the gradient behind its read
+        world = (1, 2, 4)[step - 1]
+        gd = (gs * world).to(d)
+        check(lib.dm_grad_norm(gd.data_ptr(), n, 1.0 / world, partials.data_ptr(), norm.data_ptr(), st))
         assert abs(float(norm) - float(tn)) < 1e-5 * float(tn)
         check(lib.dm_adamw_ema_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(),
                                     wb.data_ptr(), norm.data_ptr(), 1.0, n, 2e-4, 0.9, 0.99, 1e-8, 1e-2,
-                                    1 - 0.9 ** step, 1 - 0.99 ** step, decay, None, st))
+                                    1 - 0.9 ** step, 1 - 0.99 ** step, decay, None, 1.0 / world, int(step == 3), st))
+        assert torch.equal(gd.cpu(), torch.zeros(n) if step == 3 else gs * world)
         # same formulas as torch's AdamW; the global norm is reduced in a different order (rel 5e-7) and FMA
         # contraction moves results by an ulp: parameters of magnitude <= 8 agree to 2 ulps
         assert max_abs(p, ref.detach()) < 2e-6

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(dm_hip.lib, name), f"{name} declared in include/dm_hip.h but not exported"
     assert set(dm_hip.EXPORTS) == declared, set(dm_hip.EXPORTS) ^ declared
-    assert dm_hip.lib.dm_abi_version() == 2
+    assert dm_hip.lib.dm_abi_version() == 3
 
 
 def test_status_and_error_text_without_gpu():
