@@ -65,6 +65,14 @@ class BucketedAllReduce:
         # DM_DDP_DEBUG set, to every backend (RCCL's own watchdog covers the device-side wait otherwise).
         self.timeout_s = float(os.environ.get("DM_DDP_TIMEOUT", "120"))
         self.order = []  # bucket indices in the order their collectives were issued in the last step
+        # Device tensors over a backend without device collectives (gloo: the two-process tests and rehearsals that
+        # share one GPU): the reducer stages a bucket through ONE pinned host arena itself - device-to-host copy on the
+        # issuing stream when the bucket is complete, the host all-reduce and the copy back in finish() - instead of
+        # handing device tensors to the backend, whose own staging allocates pinned memory per collective and drives
+        # the HIP runtime from its worker threads. Every HIP call then comes from the caller's threads, in the order
+        # the RCCL path would issue its collectives, and the stream ordering under test is the same.
+        self.staged = self.have_group and grad_arena.is_cuda and dist.get_backend(group) != "nccl"
+        self.host = torch.empty(grad_arena.numel(), dtype=grad_arena.dtype, pin_memory=True) if self.staged else None
         self.begin()
 
     def begin(self):
@@ -118,10 +126,20 @@ class BucketedAllReduce:
             for other in sides[1:]:
                 side.wait_stream(other)
             with torch.cuda.stream(side):
-                h = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                h = self._issue(lo, hi)
         else:
-            h = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            h = self._issue(lo, hi)
         self.handles.append(h)
+
+    def _issue(self, lo, hi):
+        """The all-reduce of arena[lo:hi) on the current stream: a handle of the backend, or (staged form) the event
+        behind the bucket's copy to the host arena."""
+        if not self.staged:
+            return dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.host[lo:hi].copy_(self.grad[lo:hi], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return _Staged(self, lo, hi, ev)
 
     def finish(self, plain=False):
         """Call after backward: reduces buckets whose parameters never all reported (unused parameters) and makes
@@ -167,6 +185,22 @@ class BucketedAllReduce:
             for k, s_ in enumerate(self.extra_streams()):
                 streams[f"side{k}"] = s_
         return "streams " + ", ".join(f"{k}:{'idle' if s_.query() else 'busy'}" for k, s_ in streams.items())
+
+
+class _Staged:
+    """Handle of a bucket on its way through the pinned host arena (see BucketedAllReduce.staged)."""
+
+    def __init__(self, red, lo, hi, event):
+        self.red, self.lo, self.hi, self.event = red, lo, hi, event
+
+    def is_completed(self):
+        return self.event.query()    # the copy to the host has landed; wait() does the rest
+
+    def wait(self):
+        red = self.red
+        self.event.synchronize()
+        dist.all_reduce(red.host[self.lo:self.hi], op=dist.ReduceOp.SUM, group=red.group)
+        red.grad[self.lo:self.hi].copy_(red.host[self.lo:self.hi], non_blocking=True)
 
 
 def _debug():

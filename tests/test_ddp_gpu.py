@@ -21,6 +21,7 @@ def _worker(rank, world, port, q, side_wgrad=1, segmented=False):
     from tests.parity import det_sd_for
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("DM_TEST_WATCHDOG", "90")), exit=True)   # a stuck rank says where, instead of a silent wait
+    os.environ.setdefault("DM_DDP_TIMEOUT", "40")   # (a stuck collective reports the state of the streams before that)
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -71,9 +72,11 @@ def _worker(rank, world, port, q, side_wgrad=1, segmented=False):
             assert all(n > 0 for n in step.segment_launches), step.segment_launches
             assert world == 1 or [len(bs) for bs in step.segments[1][:-1]] == [1] * (len(step.reducer.buckets) - 1)
         torch.cuda.synchronize()
-        if world > 1:    # all but the last bucket (which holds the embedding path and the first layers) left early
+        if world > 1 and segmented != "phases":
+            # all but the last bucket (which holds the embedding path and the first layers) left while backward was
+            # running, in the order of the arena from its end
             assert early >= len(step.reducer.buckets) - 2, (early, len(step.reducer.buckets))
-            assert segmented == "phases" or step.reducer.order == list(range(len(step.reducer.buckets))), step.reducer.order
+            assert step.reducer.order == list(range(len(step.reducer.buckets))), step.reducer.order
         q.put((rank, float(loss), float(gnorm), (step.arena.data - before).cpu().numpy(), early))
     finally:
         if world > 1:
