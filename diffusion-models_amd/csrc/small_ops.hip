@@ -711,22 +711,48 @@ extern "C" int dm_transpose_conv_weights(const void* src, void* dst, const dm_wt
 
 extern "C" int dm_ordered_sum_group(const dm_sum_item* items, int n_items, void* stream) {
   DM_REQUIRE(items && n_items > 0, DM_ERR_ARG, "dm_ordered_sum_group: no items");
-  for (int i0 = 0; i0 < n_items; i0 += OS_MAX_ITEMS) {
-    OrderedSumGroup g;
-    g.count = n_items - i0 < OS_MAX_ITEMS ? n_items - i0 : OS_MAX_ITEMS;
-    int tiles = 0;
-    for (int i = 0; i < g.count; ++i) {
-      const dm_sum_item& a = items[i0 + i];
-      DM_REQUIRE(a.part && a.nparts > 0 && a.n > 0 && a.s1 >= 0 && a.s1 <= a.s2 && a.s2 <= a.n && a.stride >= a.n, DM_ERR_ARG,
-                 "dm_ordered_sum_group: item %d is malformed", i0 + i);
-      g.it[i] = a;
-      g.tile0[i] = tiles;
-      tiles += dm_cdiv(a.n, 64);
+  // The kernel adds into its outputs with a plain read-modify-write: two items of ONE launch must not share an
+  // output element (a parameter used twice in a forward pass files two sums for the same gradient). Items whose
+  // outputs overlap those of an earlier item of the launch being assembled start a new launch behind it, so they
+  // add one after the other, in item order.
+  struct Range { const float* lo; const float* hi; };
+  Range used[4 * OS_MAX_ITEMS];
+  int n_used = 0;
+  OrderedSumGroup g;
+  g.count = 0;
+  int tiles = 0;
+  auto launch = [&]() -> int {
+    if (g.count) {
+      hipLaunchKernelGGL(ordered_sum_kernel, dim3(tiles), dim3(64 * OS_WAVES), 0, (hipStream_t)stream, g);
+      DM_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(ordered_sum_kernel, dim3(tiles), dim3(64 * OS_WAVES), 0, (hipStream_t)stream, g);
-    DM_CHECK_LAUNCH();
+    g.count = 0;
+    tiles = 0;
+    n_used = 0;
+    return DM_OK;
+  };
+  for (int i = 0; i < n_items; ++i) {
+    const dm_sum_item& a = items[i];
+    DM_REQUIRE(a.part && a.nparts > 0 && a.n > 0 && a.s1 >= 0 && a.s1 <= a.s2 && a.s2 <= a.n && a.stride >= a.n, DM_ERR_ARG,
+               "dm_ordered_sum_group: item %d is malformed", i);
+    const Range mine[4] = {{a.out0, a.out0 ? a.out0 + a.s1 : nullptr}, {a.dual0, a.dual0 ? a.dual0 + a.s1 : nullptr},
+                           {a.out1, a.out1 ? a.out1 + (a.s2 - a.s1) : nullptr}, {a.out2, a.out2 ? a.out2 + (a.n - a.s2) : nullptr}};
+    bool clash = false;
+    for (int r = 0; r < 4 && !clash; ++r)
+      for (int u = 0; u < n_used && !clash; ++u)
+        clash = mine[r].lo && mine[r].lo < mine[r].hi && mine[r].lo < used[u].hi && used[u].lo < mine[r].hi;
+    if (clash || g.count == OS_MAX_ITEMS) {
+      const int rc = launch();
+      if (rc != DM_OK) return rc;
+    }
+    g.it[g.count] = a;
+    g.tile0[g.count] = tiles;
+    ++g.count;
+    tiles += dm_cdiv(a.n, 64);
+    for (int r = 0; r < 4; ++r)
+      if (mine[r].lo && mine[r].lo < mine[r].hi) used[n_used++] = mine[r];
   }
-  return DM_OK;
+  return launch();
 }
 
 int dm_finish_ordered_sum(const DmOrderedSum& a, dm_sum_item* deferred, hipStream_t st) {

@@ -50,16 +50,21 @@ class SumCollector:
     instead of launching their own sum, and flush() runs all of them in ONE launch. The partial buffers are kept
     alive until then. flush() must be called on a stream that is ordered after every producer."""
 
-    def __init__(self, capacity=512):
-        self.items = (SumItem * capacity)()
+    CHUNK = 256
+
+    def __init__(self):
+        # items live in fixed-size ctypes arrays (a producer writes through the reference slot() hands out, so an
+        # array is never moved); a model that files more sums than one array holds simply opens the next one
+        self.chunks = [(SumItem * self.CHUNK)()]
         self.count = 0
         self.keep = []
 
     def slot(self, *tensors):
         """ctypes reference to the next free item; `tensors` are the scratch buffers the item will point into."""
-        if self.count == len(self.items):
-            raise RuntimeError("SumCollector: more deferred sums than its capacity; flush() more often")
-        ref = ctypes.byref(self.items[self.count])
+        c, i = divmod(self.count, self.CHUNK)
+        if c == len(self.chunks):
+            self.chunks.append((SumItem * self.CHUNK)())
+        ref = ctypes.byref(self.chunks[c][i])
         self.count += 1
         self.keep.extend(tensors)
         return ref
@@ -69,7 +74,9 @@ class SumCollector:
             cur = torch.cuda.current_stream()
             for t in self.keep:
                 t.record_stream(cur)
-            check(lib.dm_ordered_sum_group(self.items, self.count, cur.cuda_stream))
+            for c in range((self.count + self.CHUNK - 1) // self.CHUNK):
+                n = min(self.CHUNK, self.count - c * self.CHUNK)
+                check(lib.dm_ordered_sum_group(self.chunks[c], n, cur.cuda_stream))
         self.count = 0
         self.keep = []
 

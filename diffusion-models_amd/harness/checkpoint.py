@@ -8,12 +8,19 @@ save_fid_eval.py:126-140):
     <output_dir>/train_log.jsonl, fid_evaluations.jsonl
 
 State dicts are written in the reference's tensor layout (contiguous [Cout, Cin, KH, KW] conv weights), so a
-checkpoint written here loads into the reference's UNet and vice versa.
+checkpoint written here loads into the reference's UNet and vice versa. latest.pt carries every key the reference's
+load_latest_ckpt indexes (train.py:398-413), the two host RNG states included, so the reference can resume a run
+written here; a latest.pt written by the reference (whose numpy RNG state is a pickled ndarray) is read back with the
+few numpy globals that array needs allow-listed, nothing else unpickled. No learning-rate scheduler state is kept:
+every shipped config trains without one (train.py:281-291 yields None), and the reference reads that key only when a
+scheduler is configured.
 """
 import json
 import os
+import random
 from typing import Optional
 
+import numpy as np
 import torch
 
 from diffusion.sampler import get_sampler
@@ -54,24 +61,64 @@ def _cpu(obj):
     return obj
 
 
-def save_latest_ckpt(step, output_dir: str, epochs: int = 0, steps_in_epoch: int = 0) -> str:
-    """train.py:375-392 (the host RNG states the reference adds belong to its DataLoader workers and are not kept)."""
+def _np_rng_state_plain():
+    """np.random.get_state() with the key vector as a plain list of ints: np.random.set_state accepts it as it
+    accepts the ndarray (train.py:412), and the file stays loadable with weights_only=True."""
+    name, keys, pos, has_gauss, cached = np.random.get_state()
+    return (str(name), [int(k) for k in keys], int(pos), int(has_gauss), float(cached))
+
+
+def save_latest_ckpt(step, output_dir: str, epochs: int = 0, steps_in_epoch: int = 0, dataset=None) -> str:
+    """train.py:375-392. dataset: the DeviceDataset feeding the run; the state of its flip generator is kept too
+    (the reference's flips come from its DataLoader workers' generators, which it cannot save), under a key of this
+    harness's own that the reference ignores."""
     os.makedirs(output_dir, exist_ok=True)
     ckpt = dict(_cpu(step.state_dict()), epochs=epochs, steps_in_epoch=steps_in_epoch,
-                rng_state=torch.get_rng_state(), cuda_rng_state=torch.cuda.get_rng_state())
+                rng_state=torch.get_rng_state(), cuda_rng_state=torch.cuda.get_rng_state(),
+                np_rng_state=_np_rng_state_plain(), rd_rng_state=random.getstate())
+    if dataset is not None:
+        ckpt["flip_rng_state"] = dataset.flip_gen.get_state().cpu()
     path = os.path.join(output_dir, "latest.pt")
     torch.save(ckpt, path)
     return path
 
 
-def load_latest_ckpt(step, ckpt_dir: str) -> dict:
-    """train.py:394-415. Only tensors and plain containers are read back (weights_only=True)."""
-    ckpt = torch.load(os.path.join(ckpt_dir, "latest.pt"), weights_only=True)
+def _read_latest(path):
+    """latest.pt with nothing executed from the file: tensors and plain containers only; if that refuses the file
+    because of a numpy array inside (the reference stores np.random.get_state() as is), once more with exactly the
+    globals a numpy array needs allow-listed."""
+    try:
+        return torch.load(path, weights_only=True)
+    except Exception as first:   # noqa: BLE001  (pickle.UnpicklingError carrying the refused global's name)
+        if "numpy" not in str(first):
+            raise
+        allowed = [np.ndarray, np.dtype, type(np.dtype(np.uint32))]
+        for mod in ("numpy._core.multiarray", "numpy.core.multiarray"):
+            try:
+                allowed.append(getattr(__import__(mod, fromlist=["_reconstruct"]), "_reconstruct"))
+            except (ImportError, AttributeError):
+                pass
+        with torch.serialization.safe_globals(allowed):
+            return torch.load(path, weights_only=True)
+
+
+def load_latest_ckpt(step, ckpt_dir: str, dataset=None) -> dict:
+    """train.py:394-415. Returns the checkpoint dict; its epochs / steps_in_epoch are where DeviceDataset.epochs
+    (start_epoch, start_step) takes the data order up again (the reference's skip_previous_steps, train.py:598-605)."""
+    ckpt = _read_latest(os.path.join(ckpt_dir, "latest.pt"))
     step.load_state_dict(ckpt)
     if "rng_state" in ckpt:
         torch.set_rng_state(ckpt["rng_state"])
     if "cuda_rng_state" in ckpt:
         torch.cuda.set_rng_state(ckpt["cuda_rng_state"])
+    if "np_rng_state" in ckpt:
+        name, keys, pos, has_gauss, cached = ckpt["np_rng_state"]
+        np.random.set_state((name, np.asarray(keys, dtype=np.uint32), int(pos), int(has_gauss), float(cached)))
+    if "rd_rng_state" in ckpt:
+        version, internal, gauss_next = ckpt["rd_rng_state"]
+        random.setstate((version, tuple(internal), gauss_next))
+    if dataset is not None and "flip_rng_state" in ckpt:
+        dataset.flip_gen.set_state(ckpt["flip_rng_state"].cpu())
     return ckpt
 
 

@@ -85,13 +85,23 @@ class DeviceDataset:
             self.mode = mode
         return torch.cat(parts, dim=0)
 
-    def epochs(self, batch_size: int, seed: int, drop_last: bool = False) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
-        """Endless stream of batches in the reference DataLoader's order (train.py:316-327)."""
+    def epochs(self, batch_size: int, seed: int, drop_last: bool = False, start_epoch: int = 0,
+               start_step: int = 0) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        """Endless stream of batches in the reference DataLoader's order (train.py:316-327).
+        start_epoch / start_step: take the stream up after that many whole epochs and that many batches of the next
+        one (a resumed run: the `epochs` / `steps_in_epoch` of latest.pt). The reference replays its DataLoader to get
+        there (skip_previous_steps, train.py:598-605); here the skipped epochs only advance the shuffle generator and
+        the skipped batches are never gathered. The flip generator is NOT advanced: a resumed run restores its state
+        from latest.pt (checkpoint.load_latest_ckpt(..., dataset=...))."""
         rng = torch.Generator().manual_seed(seed)
+        for _ in range(start_epoch):
+            epoch_permutation(self.N, rng)
+        first = start_step * batch_size
         while True:
             perm = epoch_permutation(self.N, rng)
-            for i in range(0, self.N, batch_size):
+            for i in range(first, self.N, batch_size):
                 idx = perm[i:i + batch_size]
                 if drop_last and idx.numel() < batch_size:
                     break
                 yield self.batch(idx)
+            first = 0

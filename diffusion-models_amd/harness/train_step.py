@@ -121,6 +121,7 @@ class TrainStep:
         self._in_backward = False
         self._report = False   # backward in progress reports finished gradients to the reducer
         self._seg = None   # state of a segmented capture in progress (capture_segmented)
+        self._update_captured = False   # update() has run under HIP-graph capture: that graph holds lr, betas, eps, wd by value
         self._replay_stream = None
         self._sums = ops.SumCollector()
         if wgrad_group is None:
@@ -382,6 +383,8 @@ class TrainStep:
         """Clip, AdamW, EMA, bf16 weight mirrors, zero the gradients (train.py:441-450)."""
         a = self.arena
         st = torch.cuda.current_stream().cuda_stream
+        if torch.cuda.is_current_stream_capturing():
+            self._update_captured = True
         # the arena holds the SUM of the ranks' gradients: the mean is taken on the fly by both kernels
         gscale = 1.0 / self.world if self.reducer.active and self.reducer.have_group else 1.0
         if self.clip > 0:
@@ -500,7 +503,12 @@ class TrainStep:
             a.view_of(self.v, i).copy_(st["exp_avg_sq"])
             steps = max(steps, int(float(st["step"])))
         g = sd["optimizer_state_dict"]["param_groups"][0]
-        self.lr, self.betas, self.eps, self.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        loaded = (g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"])
+        if self._update_captured and loaded != (self.lr, tuple(self.betas), self.eps, self.wd):
+            # those scalars are kernel arguments: a graph captured before this call would go on using the old ones
+            raise RuntimeError("load_state_dict: the checkpoint's optimizer hyper-parameters differ from the ones a captured "
+                               "update() graph holds by value; load the state before capturing, or build a new TrainStep")
+        self.lr, self.betas, self.eps, self.wd = loaded
         if self.ema is not None:
             e = sd.get("ema_model_state_dict")
             if e is None:

@@ -39,7 +39,9 @@ const char* dm_last_error(void);
  * (a null output skips its segment). The operators below that produce such sums take a `dm_sum_item* deferred`:
  * null = the ordered sum is launched at once on the same stream; non-null = the item is filled in instead and the
  * caller runs any number of them later in ONE launch with dm_ordered_sum_group, on a stream ordered after the
- * producers (the scratch must stay untouched until then). `items` is a HOST array. */
+ * producers (the scratch must stay untouched until then). `items` is a HOST array. Items of one call whose outputs
+ * overlap (a parameter used twice in one forward pass files two sums for one gradient) are added one after the other,
+ * in item order, by separate launches; immediate sums (deferred == null) into one output must be issued on ONE stream. */
 typedef struct dm_sum_item {
   const float* part;
   long stride;

@@ -409,6 +409,26 @@ def dump_samples():
     npz("samples.npz", **res)
 
 
+# 5c. ancestral sampling over ALL 1000 steps through the network (diffusion/sampler.py:50-86; what BASELINE's
+#     "sample imgs/sec @1000 steps" row runs): the variance-preserving mini network of samples.npz (its stored
+#     weights, not a retrained copy), linear beta, 4 images, sampler seed 11. The noise stream is not stored: the
+#     sampler draws it from torch.Generator().manual_seed(11) with randn_like(z) once per step but the last, which a
+#     test regenerates.
+def dump_samples_ddpm1000():
+    sys.path.insert(0, os.path.dirname(HERE))
+    from parity import trained_mini_state
+    g = np.load(os.path.join(HERE, "samples.npz"))
+    m = get_model("unet", **MINI_CFG)
+    missing = m.load_state_dict(trained_mini_state(g, "vp"), strict=False)
+    assert not missing.unexpected_keys
+    m.eval()
+    z4, cls4 = torch.from_numpy(g["z"][:4]).clone(), torch.from_numpy(g["cls"][:4]).clone()
+    lin = get_scheduler("beta", schedule="linear", n_steps=1000)
+    with torch.no_grad():
+        out = get_sampler("ddpm", n_steps=1000, pbar=False).sample(z4, lin, m.get_pred_fn(cond=cls4, guidance_scale=1.0), seed=11)
+    npz("samples_ddpm1000.npz", ddpm1000_lin=torch.clip(out, -1, 1), ddpm1000_lin_raw=out, seed=np.array(11))
+
+
 # ----------------------------------------------------------------------------------------------
 # 6. loss curve over 1000 training steps of the tiny model on a small structured data set. Only the recipe's
 #    parameters and the reference's losses are stored; tests/parity.py:curve_batches() rebuilds the batches.
@@ -452,5 +472,7 @@ if __name__ == "__main__":
         dump_train_steps("rf")
     if "samples" in which:
         dump_samples()
+    if "samples1000" in which:
+        dump_samples_ddpm1000()
     if "curve" in which:
         dump_train_curve()

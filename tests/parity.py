@@ -39,6 +39,16 @@ def trained_mini_state(g, kind):
             for k in g.files if k.startswith(prefix)}
 
 
+def ddpm_noise_stream(z, seed, n_steps):
+    """The noise DDPMSampler.sample(z, ..., seed=seed) draws (diffusion/sampler.py:60-61, 83): a fresh generator on z's
+    device seeded with `seed`, one randn_like(z) per step except the last. Regenerated on the CPU, where the
+    reference's fixtures were made."""
+    g = torch.Generator()
+    g.manual_seed(seed)
+    zc = z.cpu()
+    return torch.stack([torch.randn_like(zc, generator=g) for _ in range(n_steps - 1)])
+
+
 # ---- loss-curve recipe (tests/golden/train_curve_tiny.npz holds the reference's losses for it) -------------
 CURVE = dict(weights_seed=900, data_seed=901, steps=1000, batch=16, n_images=64, lr=5e-4)
 

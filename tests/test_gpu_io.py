@@ -120,6 +120,21 @@ def test_run_directory_roundtrip_and_resume(tmp_path):
     assert la == lb
     assert torch.equal(a.arena.data, b.arena.data) and torch.equal(a.ema, b.ema) and torch.equal(a.m, b.m)
     assert torch.equal(a.w16, b.w16) and torch.equal(a.w16_t, b.w16_t)
+    # the reference's load_latest_ckpt (train.py:394-415) finds every key it indexes, in a form its calls accept
+    import random as rd
+    ref = torch.load(os.path.join(out, "latest.pt"), weights_only=False)     # (as the reference loads it; our own file)
+    assert ref["global_steps"] == 3 and ref["epochs"] == 0 and ref["steps_in_epoch"] == 0
+    np_before, rd_before = np.random.get_state(), rd.getstate()
+    try:
+        torch.set_rng_state(ref["rng_state"])
+        torch.cuda.set_rng_state(ref["cuda_rng_state"])
+        np.random.set_state(ref["np_rng_state"])
+        rd.setstate(ref["rd_rng_state"])
+    finally:
+        np.random.set_state(np_before)
+        rd.setstate(rd_before)
+    assert set(ref["ema_model_state_dict"]) >= {"decay", "min_decay", "optimization_step", "update_after_step",
+                                                "use_ema_warmup", "inv_gamma", "power", "shadow_params"}
     # torch.optim.AdamW accepts the optimizer state as its own
     sd = torch.load(os.path.join(out, "latest.pt"), weights_only=True)
     ref_params = [torch.nn.Parameter(torch.zeros(s)) for s in a.arena.shapes]
@@ -137,6 +152,33 @@ def test_run_directory_roundtrip_and_resume(tmp_path):
     assert imgs.shape == (3, 3, 16, 16) and bool(torch.isfinite(imgs).all())
     with pytest.raises(RuntimeError):
         _step(use_ema=False).ema_state_dict()
+
+
+def test_data_order_and_flips_resume_mid_epoch(tmp_path):
+    """A run resumed from latest.pt sees the batches the uninterrupted run would have seen next: same rows (the
+    shuffle order taken up at epochs / steps_in_epoch, train.py:598-605) and the same flips (the flip generator's state
+    travels in latest.pt)."""
+    from harness import checkpoint as C
+    from harness.data import DeviceDataset
+    g = torch.Generator().manual_seed(9)
+    data = torch.randint(0, 256, (50, 8, 8, 3), generator=g, dtype=torch.uint8)
+    labels = torch.randint(0, 10, (50,), generator=g)
+    augs = ["RandomHorizontalFlip"]
+    a = DeviceDataset(data, labels, dev(), augmentations=augs, seed=7)
+    it = a.epochs(batch_size=8, seed=42)
+    per_epoch = 7                                  # ceil(50 / 8)
+    for _ in range(per_epoch + 3):                 # one whole epoch and three batches of the next
+        next(it)
+    step = _step(use_ema=False)
+    out = str(tmp_path / "run")
+    C.save_latest_ckpt(step, out, epochs=1, steps_in_epoch=3, dataset=a)
+    want = [next(it) for _ in range(per_epoch)]    # runs over the end of the epoch
+    b = DeviceDataset(data, labels, dev(), augmentations=augs, seed=12345)
+    ck = C.load_latest_ckpt(_step(seed=5, use_ema=False), out, dataset=b)
+    it2 = b.epochs(batch_size=8, seed=42, start_epoch=ck["epochs"], start_step=ck["steps_in_epoch"])
+    for (x1, y1) in want:
+        x2, y2 = next(it2)
+        assert torch.equal(x1, x2) and torch.equal(y1, y2)
 
 
 def test_fid_evaluation_log(tmp_path):

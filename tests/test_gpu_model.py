@@ -301,6 +301,35 @@ def test_generated_images_vs_reference_vp(use_graph, monkeypatch):
     _check_images(out, T(g["ddpm50_lin"]), "ddpm50_lin")
 
 
+# Bound for ancestral sampling over all 1000 steps (the long row of the benchmark): 1000 network evaluations in bf16
+# activations, each followed by fresh noise of the schedule's own size - the sampler is a contraction towards the data
+# for a trained denoiser, so the bf16 error does not accumulate beyond a few times the 50-step bound.
+SAMPLE1000_REL, SAMPLE1000_ABS = 3e-2, 1e-1
+
+
+def test_ddpm_1000_steps_vs_reference(monkeypatch):
+    """DDPM ancestral sampling, all 1000 steps of the linear-beta schedule (beta_cifar's, with sampler_type 'ddpm';
+    diffusion/sampler.py:50-86), through the reference-trained mini UNet against the reference's fp32 images, with the
+    reference's noise stream (regenerated from its seed)."""
+    from diffusion.sampler import get_sampler
+    from diffusion.scheduler import get_scheduler
+    from harness.generate import generate
+    from tests.parity import ddpm_noise_stream
+    g, m = _mini("vp")
+    ref = golden("samples_ddpm1000.npz")
+    z4, cls4 = T(g["z"])[:4], T(g["cls"])[:4]
+    noise = ddpm_noise_stream(z4, int(ref["seed"]), 1000).to(dev())
+    it = iter(range(noise.shape[0]))
+    monkeypatch.setattr(torch, "randn_like", lambda t_, generator=None: noise[next(it)])
+    lin = get_scheduler("beta", schedule="linear", n_steps=1000)
+    out = generate(m, get_sampler("ddpm", n_steps=1000, pbar=False), lin, z4, cls4, batch_size=4, use_graph=False,
+                   sampler_kwargs={"seed": int(ref["seed"])})
+    monkeypatch.undo()
+    r, a = rel_err(out, T(ref["ddpm1000_lin"])), max_abs(out, T(ref["ddpm1000_lin"]))
+    print(f"samples[ddpm1000_lin]: rel {r:.3e} max-abs {a:.3e}")
+    assert r < SAMPLE1000_REL and a < SAMPLE1000_ABS, (r, a)
+
+
 def test_generated_images_vs_reference_rf():
     """rf_cifar_long.json's scheduler and sampler (rectified flow, Euler-50) through a reference-trained velocity net."""
     from diffusion.sampler import get_sampler

@@ -5,6 +5,8 @@ Tolerances (relative L2 error against the fp32 reference, written per test): act
 (8 significant bits, unit round-off 2^-9 = 2e-3), products accumulate in fp32. fp32 kernels are held to ~1e-5;
 the diffusion elementwise kernels are bit-exact.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -358,6 +360,46 @@ def _groupnorm_case(B, C1, C2, H, W, act, ss, pre):
         assert rel_err(ssd.grad, ssr.grad) < 1e-4
     if pre:
         assert rel_err(pred_.grad, prer.grad) < 2e-4
+
+
+def test_parameter_used_twice_collects_both_gradient_terms():
+    """One GroupNorm affine pair applied twice in a forward pass files two deferred sums for the same gradient buffers:
+    the grouped ordered sum must add both (it runs items with overlapping outputs one after the other)."""
+    from dm_hip import ops
+    rs = np.random.RandomState(77)
+    B, C, H, W, G = 3, 64, 8, 8, 32
+    x = q(rnd(rs, B, C, H, W))
+    gamma, beta = 1 + 0.2 * rnd(rs, C), 0.2 * rnd(rs, C)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    h = F.silu(F.group_norm(xr, G, gr, br, eps=1e-5))
+    y_ref = F.silu(F.group_norm(q(h.detach()) + (h - h.detach()), G, gr, br, eps=1e-5))   # (the kernel's bf16 hand-over)
+    gy = q(rnd(rs, *y_ref.shape))
+    y_ref.backward(gy)
+    d = dev()
+    xd = x.to(d).requires_grad_(True)
+    gd, bd = gamma.to(d).requires_grad_(True), beta.to(d).requires_grad_(True)
+    gd.grad, bd.grad = torch.zeros_like(gd), torch.zeros_like(bd)
+    sums = ops.SumCollector()
+    y = ops.group_norm_act(ops.group_norm_act(xd, gd, bd, G, 1e-5, True), gd, bd, G, 1e-5, True)
+    ops.DIRECT_GRADS, ops.PENDING_SUMS = True, sums
+    try:
+        y.backward(gy.to(d))
+        assert sums.count == 2
+        sums.flush()
+    finally:
+        ops.DIRECT_GRADS, ops.PENDING_SUMS = False, None
+    assert rel_err(gd.grad, gr.grad) < 5e-3 and rel_err(bd.grad, br.grad) < 5e-3
+    # more deferred sums than one block of the collector holds: it grows instead of failing in the middle of backward
+    many = ops.SumCollector()
+    part = torch.ones(2, 64, device=d)
+    outs = [torch.zeros(64, device=d) for _ in range(many.CHUNK + 3)]
+    for o in outs:
+        ref_ = many.slot(part)
+        it = ref_._obj
+        it.part, it.stride, it.nparts, it.n, it.s1, it.s2 = part.data_ptr(), 64, 2, 64, 64, 64
+        it.out0, it.out1, it.out2, it.dual0 = o.data_ptr(), None, None, None
+    many.flush()
+    assert all(float(o.sum()) == 128.0 for o in outs)
 
 
 CONV_GN_CASES = [

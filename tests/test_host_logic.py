@@ -175,3 +175,37 @@ def test_bench_command_line_parses():
                          timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+
+
+def test_latest_ckpt_written_in_the_reference_form_is_read_without_unpickling_code(tmp_path):
+    """The reference stores np.random.get_state() - a tuple holding a numpy array - in latest.pt (train.py:386). Such
+    a file (written here, in that form) is read back with weights_only=True plus the handful of numpy globals the array
+    needs; a file holding anything else that would have to be executed is still refused."""
+    import random
+    import numpy as np
+    from harness.checkpoint import _np_rng_state_plain, _read_latest
+    path = str(tmp_path / "latest.pt")
+    state = np.random.get_state()
+    torch.save({"global_steps": 7, "np_rng_state": state, "rd_rng_state": random.getstate(),
+                "rng_state": torch.get_rng_state(), "model_state_dict": {"w": torch.ones(3)}}, path)
+    with pytest.raises(Exception):
+        torch.load(path, weights_only=True)                    # the plain safe loader refuses the numpy array ...
+    ck = _read_latest(path)                                    # ... the allow-listed one reads it
+    assert ck["global_steps"] == 7 and np.array_equal(ck["np_rng_state"][1], state[1])
+    # the form this harness writes needs no allow-list and np.random accepts it as it accepts the array form
+    plain = _np_rng_state_plain()
+    torch.save({"np_rng_state": plain}, path)
+    back = torch.load(path, weights_only=True)["np_rng_state"]
+    before = np.random.get_state()
+    try:
+        np.random.set_state(back)
+        assert np.array_equal(np.random.get_state()[1], before[1])
+    finally:
+        np.random.set_state(before)
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("executed",))
+    torch.save({"x": Evil()}, path)
+    with pytest.raises(Exception):
+        _read_latest(path)

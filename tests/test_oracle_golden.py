@@ -205,6 +205,25 @@ def test_samples_through_the_network():
         assert err < 1e-3, (k, err)   # summation-order differences of the fp32 kernels over 20-50 network evaluations
 
 
+def test_ddpm_1000_steps_through_the_network():
+    """Ancestral sampling over all 1000 steps (diffusion/sampler.py:50-86) through the reference-trained mini network,
+    with the sampler's own noise stream (generator seeded 11, one randn_like per step but the last) regenerated here:
+    oracle against the reference's images, fp32 on both sides."""
+    from modeling import get_model
+    from tests.parity import MINI_CFG, ddpm_noise_stream, trained_mini_state
+    g, ref = golden("samples.npz"), golden("samples_ddpm1000.npz")
+    z4, cls4 = T(g["z"])[:4], T(g["cls"])[:4]
+    base = {k: v.clone() for k, v in get_model("unet", **MINI_CFG).state_dict().items()}
+    sd = dict(base, **trained_mini_state(g, "vp"))
+    noise = ddpm_noise_stream(z4, int(ref["seed"]), 1000)
+    with torch.no_grad():
+        out = O.sample_ddpm(z4, O.beta_linear(), O.alpha_sq_from_beta(O.beta_linear()), 1000,
+                            lambda z_, t_: O.guided_pred(sd, MINI_CFG, z_, t_, cond=cls4, guidance_scale=1.0),
+                            lambda i: noise[i])
+    err = max_abs(torch.clip(out, -1, 1), T(ref["ddpm1000_lin"]))
+    assert err < 2e-3, err      # fp32 summation-order differences over 1000 network evaluations
+
+
 def test_loss_curve_head():
     """The oracle follows the reference's loss curve (first 40 of the fixture's 1000 steps; fp32 on both sides)."""
     from itertools import islice
