@@ -322,7 +322,11 @@ def sampling_row(model, cfg, device, rank, world, config_name, sampler_type=None
             "tflops": round(tf, 1) if tf else None,
             "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4) if tf else None, "hip_graph": bool(use_graph),
             "interleaved_sub_batches": chains,
-            "activations": "bf16 (the reference samples in fp32)"}
+            # the reference samples in fp32; bound of the difference measured on reference-trained networks against
+            # the reference's own images (tests/test_gpu_model.py): relative L2 <= 6.2e-3 over DDIM-50 / Euler-50,
+            # 8.9e-5 over DDPM ancestral sampling with all 1000 steps
+            "activations": "bf16 (the reference samples in fp32)",
+            "image_error_bound_vs_fp32_reference": 1e-3 if (stype == "ddpm" and n >= 1000) else 1.5e-2}
 
 
 def bench_sampling(args, cfg, device, rank, world):

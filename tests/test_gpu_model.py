@@ -302,9 +302,10 @@ def test_generated_images_vs_reference_vp(use_graph, monkeypatch):
 
 
 # Bound for ancestral sampling over all 1000 steps (the long row of the benchmark): 1000 network evaluations in bf16
-# activations, each followed by fresh noise of the schedule's own size - the sampler is a contraction towards the data
-# for a trained denoiser, so the bf16 error does not accumulate beyond a few times the 50-step bound.
-SAMPLE1000_REL, SAMPLE1000_ABS = 3e-2, 1e-1
+# activations, each followed by fresh noise of the schedule's own size. For a trained denoiser the sampler is a
+# contraction towards the data and the last hundred steps (small beta) decide the image, so the bf16 error does not
+# accumulate: it ends far BELOW the 50-step DDIM bound.
+SAMPLE1000_REL, SAMPLE1000_ABS = 1e-3, 5e-3   # measured: rel 8.9e-5, worst pixel 5.6e-4
 
 
 def test_ddpm_1000_steps_vs_reference(monkeypatch):
