@@ -96,7 +96,7 @@ HBM_OPS = {
     "dm_mse_loss_bwd": ("mse_bwd (loss gradient)", lambda a: (16.0 if a[1] else 12.0) * a[5]),
     "dm_sampler_step": ("sampler_step (DDPM/DDIM/Euler update)", lambda a: (16.0 if a[2] else 12.0) * a[10]),
 }
-CONV_OPS = ("dm_conv2d_igemm", "dm_conv2d_igemm_gn", "dm_conv2d_wgrad", "dm_conv2d_wgrad_group")
+CONV_OPS = ("dm_conv2d_igemm", "dm_conv2d_igemm_gn", "dm_conv2d_igemm_proj", "dm_conv2d_wgrad", "dm_conv2d_wgrad_group")
 # Kernels of a few microseconds: an event bracket around ONE eager call times the host's launch path, not the kernel.
 # These are timed as BURST launches of the same call replayed from a HIP graph (idempotent or throw-away outputs).
 BURST_OPS = ("dm_diffuse", "dm_mse_loss_fwd", "dm_mse_loss_bwd", "dm_sampler_step", "dm_grad_norm")
@@ -135,7 +135,11 @@ class AbiTimer:
                 work = 2.0 * m * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
                 # algorithmic bytes: every operand once (input, weights, output, residual of the fused epilogue)
                 nbytes = 2.0 * (d.B * d.Hs * d.Ws * (d.C1 + d.C2) + d.Cout * d.KH * d.KW * (d.C1 + d.C2) + m * d.Cout)
-                if name.startswith("dm_conv2d_igemm") and args[5]:
+                if name == "dm_conv2d_igemm_proj":   # + the 1x1 projection of the second input, in the same launch
+                    pr = args[5]._obj
+                    work += 2.0 * m * d.Cout * (pr.C1 + pr.C2)
+                    nbytes += 2.0 * (m * (pr.C1 + pr.C2) + d.Cout * (pr.C1 + pr.C2))
+                elif name.startswith("dm_conv2d_igemm") and args[5]:
                     nbytes += 2.0 * m * d.Cout
                 if name == "dm_conv2d_igemm_gn":    # the normalised tensor as well; flops: the convolution's only
                     nbytes += 2.0 * m * d.Cout
@@ -543,10 +547,11 @@ def main():
                 get_sampler("euler", n_steps=3, pbar=False).sample(zz, sched, fake)
         summ = ct.summary()
         ig = {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0}
-        for key in ("dm_conv2d_igemm", "dm_conv2d_igemm_gn"):
+        for key in ("dm_conv2d_igemm", "dm_conv2d_igemm_gn", "dm_conv2d_igemm_proj"):
             for k, v in summ.get(key, {}).items():
                 ig[k] += v
         fused_gn = summ.get("dm_conv2d_igemm_gn", {}).get("launches", 0)
+        fused_proj = summ.get("dm_conv2d_igemm_proj", {}).get("launches", 0)
         wg = {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0}
         for key in ("dm_conv2d_wgrad", "dm_conv2d_wgrad_group"):
             for k, v in summ.get(key, {}).items():
@@ -556,9 +561,10 @@ def main():
             traffic = measured_conv_traffic()
             roof = {"bound": "mfma",
                     "kernel": "conv_patch_kernel<128,6> / conv_patch_kernel<64,7> / conv_igemm_kernel<128>: every "
-                              "dm_conv2d_igemm / dm_conv2d_igemm_gn launch of a step (forward + data gradient; "
+                              "dm_conv2d_igemm / _gn / _proj launch of a step (forward + data gradient; "
                               f"{fused_gn} of them carry the following GroupNorm in their epilogue, priced at the "
-                              "convolution's flops alone)",
+                              f"convolution's flops alone; {fused_proj} carry a block's 1x1 residual projection, priced "
+                              "with its flops)",
                     "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "bytes/launch",

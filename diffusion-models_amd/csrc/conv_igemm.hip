@@ -263,16 +263,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(ConvArgs a) {
 int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
                       const void* res, void* y, hipStream_t st, const dm_gn_desc* g, const float* gamma,
                       const float* beta, const float* ss, const float* pre, void* y_norm, float* mean,
-                      float* rstd);
+                      float* rstd, const dm_conv_proj* proj);
 int dm_conv_patch_gn_ok(const dm_conv_desc* d, const dm_gn_desc* g);
+int dm_conv_patch_proj_ok(const dm_conv_desc* d, const dm_conv_proj* p);
 extern int g_dm_use_patch_kernel;
 extern int g_dm_conv_gn_fuse;
 extern int g_dm_dgrad_subpixel;
+extern int g_dm_conv_proj_fuse;
 
 static int conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
                         const void* res, void* y, void* stream, const dm_gn_desc* g, const float* gamma,
                         const float* beta, const float* ss, const float* pre, void* y_norm, float* mean,
-                        float* rstd);
+                        float* rstd, const dm_conv_proj* proj = nullptr);
+
+extern "C" int dm_conv2d_proj_fusable(const dm_conv_desc* d, const dm_conv_proj* p) {
+  return d && p && g_dm_use_patch_kernel && g_dm_conv_proj_fuse && dm_conv_patch_proj_ok(d, p);
+}
+
+extern "C" int dm_conv2d_igemm_proj(const dm_conv_desc* d, const void* x1, const void* x2, const void* w,
+                                    const float* bias, const dm_conv_proj* p, void* y, void* stream) {
+  DM_REQUIRE(p && p->x1 && p->w, DM_ERR_ARG, "dm_conv2d_igemm_proj: null argument");
+  DM_REQUIRE((p->C2 == 0) == (p->x2 == nullptr), DM_ERR_ARG, "dm_conv2d_igemm_proj: projection x2 and C2 disagree");
+  DM_REQUIRE(((uintptr_t)p->x1 | (uintptr_t)p->x2 | (uintptr_t)p->w | (uintptr_t)p->bias) % 16 == 0, DM_ERR_ARG,
+             "dm_conv2d_igemm_proj: pointers must be 16-byte aligned");
+  DM_REQUIRE(dm_conv2d_proj_fusable(d, p), DM_ERR_UNSUPPORTED,
+             "dm_conv2d_igemm_proj: this layer does not take the fused projection (ask dm_conv2d_proj_fusable first)");
+  return conv2d_igemm(d, x1, x2, w, bias, nullptr, y, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      nullptr, p);
+}
 
 extern "C" int dm_conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const void* w,
                                const float* bias, const void* res, void* y, void* stream) {
@@ -300,7 +318,7 @@ extern "C" int dm_conv2d_igemm_gn(const dm_conv_desc* d, const void* x1, const v
 static int conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
                         const void* res, void* y, void* stream, const dm_gn_desc* g, const float* gamma,
                         const float* beta, const float* ss, const float* pre, void* y_norm, float* mean,
-                        float* rstd) {
+                        float* rstd, const dm_conv_proj* proj) {
   DM_REQUIRE(d && x1 && w && y, DM_ERR_ARG, "dm_conv2d_igemm: null argument");
   DM_REQUIRE(d->C1 > 0 && d->C1 % BK == 0 && d->C2 >= 0 && d->C2 % BK == 0, DM_ERR_SHAPE,
              "dm_conv2d_igemm: input channels (%d, %d) must be multiples of %d", d->C1, d->C2, BK);
@@ -331,11 +349,11 @@ static int conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, c
   // 3x3 stride-1 convs (and their data gradients) go to the LDS-staged-patch kernel when the shape allows
   if (g_dm_use_patch_kernel &&
       dm_conv_patch_try(d, x1, x2, w, bias, res, y, (hipStream_t)stream, g, gamma, beta, ss, pre, y_norm, mean,
-                        rstd) == DM_OK) {
+                        rstd, proj) == DM_OK) {
     DM_CHECK_LAUNCH();
     return DM_OK;
   }
-  DM_REQUIRE(!g, DM_ERR_UNSUPPORTED, "dm_conv2d_igemm_gn: layer not covered by the patch kernel");
+  DM_REQUIRE(!g && !proj, DM_ERR_UNSUPPORTED, "dm_conv2d_igemm_gn/_proj: layer not covered by the patch kernel");
 
   ConvArgs a;
   a.x1 = x1; a.x2 = x2; a.w = w; a.bias = bias; a.res = res; a.y = y;

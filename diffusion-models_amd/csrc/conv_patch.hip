@@ -50,6 +50,14 @@ struct PatchArgs {
   float* gn_rstd;
   int gn_hw, gn_G, gn_cg, gn_act;
   float gn_eps;
+  // optional 1x1 projection of a second input (the block's residual branch, modeling/blocks.py:74-75) accumulated
+  // into the same output tile behind the 3x3 taps (pw != null): p1 | p2 are [B][H][W][PC1 | PC2], pw is [Cout][PCin]
+  const void* p1;
+  const void* p2;
+  const void* pw;
+  const float* pbias;
+  int PC1, PC2, PCin;
+  unsigned p1_bytes, p2_bytes, pw_bytes;
 };
 
 template <int BN, int NP>
@@ -96,7 +104,10 @@ __device__ __forceinline__ void frags_wait(f32x4_t (&a)[MI_], f32x4_t (&b)[NJ_])
                  : "n"(N));
 }
 
-template <int BN, int NP>
+// PROJ: the instantiation that also carries the fused 1x1 projection (a.pw != null). Its own instantiation, so that the
+// plain kernels keep their register count (what a CU has left beside two of their waves per SIMD is what the other
+// stream's HBM-bound kernels run in).
+template <int BN, int NP, bool PROJ>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
   using L = Lay<BN, NP>;
   constexpr int WN = BN / 2, NJ = WN / 16, MI = 4, BP = L::B_PIECES;
@@ -132,6 +143,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
   // half see 8 different columns mod 8 (a pixel-index key collides on 8-wide images: the row pitch is 10).
   int akey[NP];
   int gsrc[NP];                                // source pixel index, -1: zero
+  unsigned own = 0;                            // bit i: piece i is a pixel of the tile itself (not a halo pixel)
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int pp = spix + 64 * i;
@@ -148,6 +160,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
     const int yin = ystart - 1 + local, xin = pc - 1, b = b0 + k;
     const bool ok = xin >= 0 && xin < a.W && yin >= 0 && yin < a.H && b < a.B;
     gsrc[i] = ok ? ((b * a.Hs + (yin >> a.ups)) * a.Ws + (xin >> a.ups)) : -1;
+    if (PROJ && ok && local >= 1 && local <= (k == 0 ? nrow0 : a.H)) own |= 1u << i;
   }
   unsigned wrow[BP];
 #pragma unroll
@@ -309,6 +322,74 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
 
   if (SHIFT && !lead) multiply();
 
+  // ---- the residual branch's 1x1 projection, accumulated into the same tile: per 64-channel chunk of the second
+  // input the tile's own pixels go into a patch buffer (halo pieces load zeros without touching memory) and the
+  // projection's weights into a ring stage; the centre tap's fragment addresses read them. One chunk ahead, both
+  // wave groups in phase: the chunk is bound by its loads (48 KB for 32 MFMAs per wave), not by the matrix core.
+  if constexpr (PROJ) {
+    __amdgpu_buffer_rsrc_t rp1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.p1), 0, a.p1_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rp2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.p2 ? a.p2 : a.p1), 0,
+                                                                   a.p2 ? a.p2_bytes : 0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t rpw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.pw), 0, a.pw_bytes, 0x00020000);
+    unsigned prow[BP];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const int n = n0 + (tid >> 3) + 64 * i;
+      const int chunkB = (tid & 7) ^ ((tid >> 3) & 7);
+      prow[i] = (n < a.Cout) ? (unsigned)(n * a.PCin * 2 + chunkB * 16) : DM_OOB;
+    }
+    auto issue_proj = [&](int cc, int buf) {
+      const bool second = cc >= a.PC1;
+      const int csrc = second ? a.PC2 : a.PC1, coff = second ? cc - a.PC1 : cc;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const unsigned off = ((own >> i) & 1u) ? (unsigned)(gsrc[i] * csrc * 2 + coff * 2 + akey[i] * 16) : DM_OOB;
+        char* dst = smem + (buf ? L::A1 : L::A0) + (wave * 64 + NTHREADS * i) * 16;
+        if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rp2, DM_LDS(dst), 16, off, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rp1, DM_LDS(dst), 16, off, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < BP; ++i) {
+        const unsigned off = prow[i] == DM_OOB ? DM_OOB : prow[i] + (unsigned)(cc * 2);
+        char* dst = smem + L::B0 + buf * L::B_BYTES + (wave * 64 + NTHREADS * i) * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rpw, DM_LDS(dst), 16, off, 0, 0, 0);
+      }
+    };
+    // the main loop's trailing loads have landed and every wave has read its last fragments
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int npc = a.PCin / BK;
+    issue_proj(0, 0);
+    for (int c = 0; c < npc; ++c) {
+      if (c + 1 < npc) {
+        issue_proj((c + 1) * BK, (c + 1) & 1);
+        wait_vmcnt<NP + BP>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const unsigned abase = lds_base + ((c & 1) ? L::A1 : L::A0);
+      const unsigned bbase = lds_base + L::B0 + (c & 1) * L::B_BYTES;
+      const int toff = a.PW + 1;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          lds_read128(af[kk][i], abase + ((pA[i] + toff) << 7) + ((((kk * 4 + fq) ^ (xA[i] + 1)) & 7) << 4));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) lds_read128(bfr[kk][j], bbase + b_off[j][kk]);
+      }
+      multiply();
+      // every wave is done with this chunk's buffers before the next iteration refills them
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  }
+
   // ---- epilogue (the trailing dummy loads must have landed before LDS is reused)
   wait_vmcnt<0>();
   __syncthreads();
@@ -334,6 +415,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     if (a.bias) {
       const f32x4_t c0 = *(const f32x4_t*)(a.bias + n), c1 = *(const f32x4_t*)(a.bias + n + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] += c0[j]; v[4 + j] += c1[j]; }
+    }
+    if (PROJ && a.pbias) {
+      const f32x4_t c0 = *(const f32x4_t*)(a.pbias + n), c1 = *(const f32x4_t*)(a.pbias + n + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v[j] += c0[j]; v[4 + j] += c1[j]; }
     }
@@ -550,10 +636,23 @@ int dm_conv_patch_gn_ok(const dm_conv_desc* d, const dm_gn_desc* g) {
   return g && gn_plan(d, g, bn64, TR);
 }
 
+// Can the 1x1 projection `p` of a second input ride in this layer's patch kernel? (a regular 3x3 convolution that
+// takes the patch kernel, no fused upsampling; projection channels in whole 64-channel chunks per source)
+int dm_conv_patch_proj_ok(const dm_conv_desc* d, const dm_conv_proj* p) {
+  bool bn64;
+  int TR;
+  if (!d || !p || d->transposed || d->ups) return 0;
+  patch_plan(d, bn64, TR);
+  if (!TR) return 0;
+  if (p->C1 <= 0 || p->C1 % BK || p->C2 < 0 || p->C2 % BK) return 0;
+  const long npix = (long)d->B * d->Ho * d->Wo;
+  return npix * p->C1 * 2 < 0x7fffffffL && npix * p->C2 * 2 < 0x7fffffffL && (long)d->Cout * (p->C1 + p->C2) * 2 < 0x7fffffffL;
+}
+
 int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
                       const void* res, void* y, hipStream_t st, const dm_gn_desc* g, const float* gamma,
                       const float* beta, const float* ss, const float* pre, void* y_norm, float* mean,
-                      float* rstd) {
+                      float* rstd, const dm_conv_proj* proj) {
   bool bn64;
   int TR;
   if (g) {
@@ -562,6 +661,7 @@ int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, con
     patch_plan(d, bn64, TR);
   }
   if (!TR) return DM_ERR_UNSUPPORTED;
+  if (proj && !dm_conv_patch_proj_ok(d, proj)) return DM_ERR_UNSUPPORTED;
   const int H = d->Ho, W = d->Wo, Cin = d->C1 + d->C2;
   const long M = (long)d->B * H * W;
 
@@ -575,6 +675,17 @@ int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, con
   a.x1_bytes = (unsigned)(npix_src * d->C1 * 2);
   a.x2_bytes = (unsigned)(npix_src * d->C2 * 2);
   a.w_bytes = (unsigned)((long)d->Cout * 9 * Cin * 2);
+  a.p1 = a.p2 = a.pw = nullptr;
+  a.pbias = nullptr;
+  a.PC1 = a.PC2 = a.PCin = 0;
+  a.p1_bytes = a.p2_bytes = a.pw_bytes = 0;
+  if (proj) {
+    a.p1 = proj->x1; a.p2 = proj->x2; a.pw = proj->w; a.pbias = proj->bias;
+    a.PC1 = proj->C1; a.PC2 = proj->C2; a.PCin = proj->C1 + proj->C2;
+    a.p1_bytes = (unsigned)(M * proj->C1 * 2);
+    a.p2_bytes = (unsigned)(M * proj->C2 * 2);
+    a.pw_bytes = (unsigned)((long)d->Cout * a.PCin * 2);
+  }
   a.gn_y = nullptr;
   a.gn_gamma = a.gn_beta = a.gn_ss = a.gn_pre = nullptr;
   a.gn_mean = a.gn_rstd = nullptr;
@@ -588,10 +699,12 @@ int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, con
   const int mt_pad = (a.n_mtiles + 7) / 8 * 8;
   if (bn64) {
     a.n_ntiles = dm_cdiv(d->Cout, 64);
-    hipLaunchKernelGGL((conv_patch_kernel<64, 7>), dim3(mt_pad * a.n_ntiles), dim3(NTHREADS), 0, st, a);
+    if (proj) hipLaunchKernelGGL((conv_patch_kernel<64, 7, true>), dim3(mt_pad * a.n_ntiles), dim3(NTHREADS), 0, st, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<64, 7, false>), dim3(mt_pad * a.n_ntiles), dim3(NTHREADS), 0, st, a);
   } else {
     a.n_ntiles = dm_cdiv(d->Cout, 128);
-    hipLaunchKernelGGL((conv_patch_kernel<128, 6>), dim3(mt_pad * a.n_ntiles), dim3(NTHREADS), 0, st, a);
+    if (proj) hipLaunchKernelGGL((conv_patch_kernel<128, 6, true>), dim3(mt_pad * a.n_ntiles), dim3(NTHREADS), 0, st, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<128, 6, false>), dim3(mt_pad * a.n_ntiles), dim3(NTHREADS), 0, st, a);
   }
   return DM_OK;
 }

@@ -23,6 +23,7 @@ int g_dm_gn_fused = 1;
 int g_dm_use_wgrad9 = 0;              // 3x3 weight gradients with all nine taps per workgroup (1: >= 512 input channels, 3: also >= 256 on >= 16x16 images, 2: wherever the shape allows). Off: faster alone, but the step is slower (its 236 VGPRs leave no room on a SIMD for the other stream's GroupNorm waves)
 int g_dm_dgrad_subpixel = 1;          // stride-2 data gradients by output-pixel parity class (only the taps a class meets)
 int g_dm_conv_gn_fuse = 1;            // GroupNorm(+SiLU) that follows a 3x3 conv in that conv's epilogue where a tile holds whole samples
+int g_dm_conv_proj_fuse = 1;          // a ConvBlock's 1x1 residual projection inside its second 3x3 convolution's launch
 int g_dm_edge_mfma = 1;               // UNet edge convs (image <-> features): matrix-core kernels instead of the VALU ones
 int g_dm_attn_mfma = 1;              // head dims 8 / 16: attention core on the matrix cores
 int g_dm_gn_bwd16 = 1;               // 513..1024-pixel GroupNorm backward: 512 threads x 16 pixels (no spills) instead of 1024 x 8
@@ -36,7 +37,7 @@ const Switch kSwitches[] = {
   {"gn_fused", &g_dm_gn_fused, 1},               {"conv_gn_fuse", &g_dm_conv_gn_fuse, 1},
   {"wgrad_row9", &g_dm_use_wgrad9, 0},           {"dgrad_subpixel", &g_dm_dgrad_subpixel, 1},
   {"edge_mfma", &g_dm_edge_mfma, 1},             {"attn_mfma", &g_dm_attn_mfma, 1},
-  {"gn_bwd16", &g_dm_gn_bwd16, 1},
+  {"gn_bwd16", &g_dm_gn_bwd16, 1},               {"conv_proj_fuse", &g_dm_conv_proj_fuse, 1},
 };
 const Switch* find_switch(const char* key) {
   if (key)

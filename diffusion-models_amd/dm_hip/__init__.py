@@ -30,6 +30,11 @@ class GnDesc(ctypes.Structure):
                 ("act", c_int), ("has_ss", c_int), ("has_pre", c_int)]
 
 
+class ConvProj(ctypes.Structure):
+    """dm_conv_proj: the 1x1 projection of a second input that rides in a 3x3 convolution's launch."""
+    _fields_ = [("x1", c_void_p), ("x2", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("C1", c_int), ("C2", c_int)]
+
+
 class LinearItem(ctypes.Structure):
     _fields_ = [("w", c_void_p), ("b", c_void_p), ("y", c_void_p), ("dy", c_void_p), ("dw", c_void_p),
                 ("db", c_void_p), ("N", c_int)]
@@ -60,6 +65,8 @@ _SIGNATURES = {
     "dm_conv2d_igemm": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "dm_conv2d_gn_fusable": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(GnDesc)]),
     "dm_conv2d_igemm_gn": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, ctypes.POINTER(GnDesc)] + [P] * 8),
+    "dm_conv2d_proj_fusable": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvProj)]),
+    "dm_conv2d_igemm_proj": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ConvProj), P, P]),
     "dm_conv2d_wgrad_ws_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "dm_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, ctypes.c_size_t, P]),
     "dm_conv2d_wgrad_group_ws_bytes": (ctypes.c_size_t, [P, c_int]),

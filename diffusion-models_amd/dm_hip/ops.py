@@ -10,7 +10,7 @@ import os
 import torch
 from torch.autograd import Function
 
-from . import ConvDesc, GnDesc, LinearItem, SumItem, WgradItem, check, lib
+from . import ConvDesc, ConvProj, GnDesc, LinearItem, SumItem, WgradItem, check, lib
 
 BF16 = torch.bfloat16
 CL = torch.channels_last
@@ -474,90 +474,100 @@ class _ConvFn(Function):
     @staticmethod
     def backward(ctx, dy, *_unused):
         x1, x2, weight = ctx.saved_tensors
-        stride, pad, ups, pack, has_bias, has_res, dims = ctx.cfg
-        B, C1, C2, Hs, Ws, Hi, Wi, Ho, Wo = dims
-        w4 = weight if weight.dim() == 4 else weight[:, :, None, None]
-        Cout, Cin, KH, KW = w4.shape
-        if dy is None:
-            dy = torch.zeros((B, Cout, Ho, Wo), dtype=BF16, device=x1.device)
-        dy = as_nhwc(dy)
-        st = _stream()
-        dx1 = dx2 = dw = db = None
-        done = []
-        wparam, bparam = ctx.params
-        wsink = _grad_sink(wparam, ohwi=True) if ctx.needs_input_grad[2] else None
-        want_db = has_bias and ctx.needs_input_grad[3]
-        bsink = _grad_sink(bparam) if want_db else None
-        on_side = (wsink is not None or not ctx.needs_input_grad[2]) and (bsink is not None or not want_db)
-        st_w, stream_w = _param_stream((dy, x1, x2), on_side)   # dy (and the saved inputs) are complete
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            _, w_dgrad = pack.get(weight)
-            dxf = empty_nhwc(B, Cin, Hi, Wi, dy.device)
-            d = _conv_desc(B, Ho, Wo, Cout, 0, Cin, KH, KW, stride, pad, 0, 1, Hi, Wi)
-            # the gradient a skip connection's late consumer left for this input rides the epilogue's residual add
-            late = ctx.box.take((B, Cin, Hi, Wi)) if ctx.box is not None else None
-            check(lib.dm_conv2d_igemm(ctypes.byref(d), dy.data_ptr(), None, w_dgrad.data_ptr(), None, _p(late),
-                                      dxf.data_ptr(), st))
-            if ups:
-                dxs = empty_nhwc(B, Cin, Hs, Ws, dy.device)
-                check(lib.dm_upsample2x_bwd(dxf.data_ptr(), dxs.data_ptr(), B, Hs, Ws, Cin, st))
-                dxf = dxs
-            if x2 is None:
-                dx1 = dxf
-            else:
-                dx1, dx2 = dxf[:, :C1], dxf[:, C1:]
-        if ctx.needs_input_grad[2]:
-            dwf = wsink if wsink is not None else torch.zeros((Cout, KH, KW, Cin), dtype=torch.float32, device=dy.device)
-            d = _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, 0, Ho, Wo)
-            # split-K partial tiles go through a scratch workspace (no float atomics, order-independent sums),
-            # allocated on the stream that runs the kernel
-            if wsink is not None and PENDING_WGRADS is not None:
-                PENDING_WGRADS.add(d, x1, x2, dy, dwf, wparam)   # launched with its neighbours; reports the parameter then
-            else:
-                ws_bytes = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(d))
-                ws = _scratch(dy.device, (ws_bytes + 3) // 4, stream_w)
-                check(lib.dm_conv2d_wgrad(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(),
-                                          ws.data_ptr(), ws.numel() * 4, st_w))
-                if wsink is not None:
-                    done.append(wparam)
-            if wsink is None:
-                dw = dwf.permute(0, 3, 1, 2)
-                if weight.dim() == 2:
-                    dw = dw.reshape(Cout, Cin)
-        if want_db:
-            dbf = bsink if bsink is not None else torch.zeros(Cout, dtype=torch.float32, device=dy.device)
-            twin = ctx.bias_twin
-            tsink = _grad_sink(twin) if (twin is not None and bsink is not None) else None
-            M = B * Ho * Wo
-            cws = _scratch(dy.device, lib.dm_colsum_ws_floats(M, Cout), stream_w)
-            if tsink is not None:
-                # the twin's convolution produced the other term of the same sum (and ran with bias_grad=False)
-                check(lib.dm_colsum_bf16_dual(dy.data_ptr(), dbf.data_ptr(), tsink.data_ptr(), M, Cout, cws.data_ptr(),
-                                              _deferred(True, cws), st_w))
-                done.append(twin)
-            else:
-                check(lib.dm_colsum_bf16(dy.data_ptr(), dbf.data_ptr(), M, Cout, cws.data_ptr(),
-                                         _deferred(bsink is not None and twin is None, cws), st_w))
-                if twin is not None:
-                    g = dbf.detach().to(twin.dtype)
-                    if twin.grad is None:
-                        twin.grad = g.clone()
-                    else:
-                        twin.grad.add_(g)   # in place: a gradient that is a view of a flat arena stays one
-            if bsink is not None:
-                done.append(bparam)
-            else:
-                db = dbf
-        # reported only now, after this operator's last launch: a listener may close a HIP-graph capture at such a
-        # report, and the side stream forked above belongs to the capture that was open then
-        for prm in done:
-            _grad_done(prm)
-        if PENDING_WGRADS is not None:
-            PENDING_WGRADS.flush_if_full()
-        dres = dy if (has_res and ctx.needs_input_grad[4]) else None
-        if dres is not None and (stream_w is not None or SIDE_WGRAD):
-            SIDE_KEEP.append(dy)
+        dx1, dx2, dw, db, dres = _conv_backward(x1, x2, weight, ctx.params, ctx.bias_twin, ctx.box, ctx.cfg, dy,
+                                                ctx.needs_input_grad[:5])
         return dx1, dx2, dw, db, dres, None, None, None, None, None, None, None, None
+
+
+def _conv_backward(x1, x2, weight, params, bias_twin, box, cfg, dy, needs):
+    """Backward of one convolution y = conv(x1 | x2) + bias (+ res): the data gradient on the current stream, the
+    weight / bias gradients on a side stream when the caller set that mode up. needs: which of (x1, x2, weight, bias,
+    res) want a gradient. Returns (dx1, dx2, dw, db, dres); dw / db are None when the gradient went straight into the
+    parameter's gradient buffer."""
+    stride, pad, ups, pack, has_bias, has_res, dims = cfg
+    B, C1, C2, Hs, Ws, Hi, Wi, Ho, Wo = dims
+    w4 = weight if weight.dim() == 4 else weight[:, :, None, None]
+    Cout, Cin, KH, KW = w4.shape
+    if dy is None:
+        dy = torch.zeros((B, Cout, Ho, Wo), dtype=BF16, device=x1.device)
+    dy = as_nhwc(dy)
+    st = _stream()
+    dx1 = dx2 = dw = db = None
+    done = []
+    wparam, bparam = params
+    wsink = _grad_sink(wparam, ohwi=True) if needs[2] else None
+    want_db = has_bias and needs[3]
+    bsink = _grad_sink(bparam) if want_db else None
+    on_side = (wsink is not None or not needs[2]) and (bsink is not None or not want_db)
+    st_w, stream_w = _param_stream((dy, x1, x2), on_side)   # dy (and the saved inputs) are complete
+    if needs[0] or needs[1]:
+        _, w_dgrad = pack.get(weight)
+        dxf = empty_nhwc(B, Cin, Hi, Wi, dy.device)
+        d = _conv_desc(B, Ho, Wo, Cout, 0, Cin, KH, KW, stride, pad, 0, 1, Hi, Wi)
+        # the gradient a skip connection's late consumer left for this input rides the epilogue's residual add
+        late = box.take((B, Cin, Hi, Wi)) if box is not None else None
+        check(lib.dm_conv2d_igemm(ctypes.byref(d), dy.data_ptr(), None, w_dgrad.data_ptr(), None, _p(late),
+                                  dxf.data_ptr(), st))
+        if ups:
+            dxs = empty_nhwc(B, Cin, Hs, Ws, dy.device)
+            check(lib.dm_upsample2x_bwd(dxf.data_ptr(), dxs.data_ptr(), B, Hs, Ws, Cin, st))
+            dxf = dxs
+        if x2 is None:
+            dx1 = dxf
+        else:
+            dx1, dx2 = dxf[:, :C1], dxf[:, C1:]
+    if needs[2]:
+        dwf = wsink if wsink is not None else torch.zeros((Cout, KH, KW, Cin), dtype=torch.float32, device=dy.device)
+        d = _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, 0, Ho, Wo)
+        # split-K partial tiles go through a scratch workspace (no float atomics, order-independent sums),
+        # allocated on the stream that runs the kernel
+        if wsink is not None and PENDING_WGRADS is not None:
+            PENDING_WGRADS.add(d, x1, x2, dy, dwf, wparam)   # launched with its neighbours; reports the parameter then
+        else:
+            ws_bytes = lib.dm_conv2d_wgrad_ws_bytes(ctypes.byref(d))
+            ws = _scratch(dy.device, (ws_bytes + 3) // 4, stream_w)
+            check(lib.dm_conv2d_wgrad(ctypes.byref(d), x1.data_ptr(), _p(x2), dy.data_ptr(), dwf.data_ptr(),
+                                      ws.data_ptr(), ws.numel() * 4, st_w))
+            if wsink is not None:
+                done.append(wparam)
+        if wsink is None:
+            dw = dwf.permute(0, 3, 1, 2)
+            if weight.dim() == 2:
+                dw = dw.reshape(Cout, Cin)
+    if want_db:
+        dbf = bsink if bsink is not None else torch.zeros(Cout, dtype=torch.float32, device=dy.device)
+        twin = bias_twin
+        tsink = _grad_sink(twin) if (twin is not None and bsink is not None) else None
+        M = B * Ho * Wo
+        cws = _scratch(dy.device, lib.dm_colsum_ws_floats(M, Cout), stream_w)
+        if tsink is not None:
+            # the twin's convolution produced the other term of the same sum (and ran with bias_grad=False)
+            check(lib.dm_colsum_bf16_dual(dy.data_ptr(), dbf.data_ptr(), tsink.data_ptr(), M, Cout, cws.data_ptr(),
+                                          _deferred(True, cws), st_w))
+            done.append(twin)
+        else:
+            check(lib.dm_colsum_bf16(dy.data_ptr(), dbf.data_ptr(), M, Cout, cws.data_ptr(),
+                                     _deferred(bsink is not None and twin is None, cws), st_w))
+            if twin is not None:
+                g = dbf.detach().to(twin.dtype)
+                if twin.grad is None:
+                    twin.grad = g.clone()
+                else:
+                    twin.grad.add_(g)   # in place: a gradient that is a view of a flat arena stays one
+        if bsink is not None:
+            done.append(bparam)
+        else:
+            db = dbf
+    # reported only now, after this operator's last launch: a listener may close a HIP-graph capture at such a
+    # report, and the side stream forked above belongs to the capture that was open then
+    for prm in done:
+        _grad_done(prm)
+    if PENDING_WGRADS is not None:
+        PENDING_WGRADS.flush_if_full()
+    dres = dy if (has_res and needs[4]) else None
+    if dres is not None and (stream_w is not None or SIDE_WGRAD):
+        SIDE_KEEP.append(dy)
+    return dx1, dx2, dw, db, dres
 
 
 def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0, bias_grad=True, bias_twin=None,
@@ -576,6 +586,64 @@ def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0, bi
     if norm is None:
         return y
     return y, ((y_norm, mean, rstd) if y_norm is not None else None)
+
+
+class _ConvProjFn(Function):
+    """y = conv3x3(h, weight) + bias + conv1x1(r1 | r2, wr) + br in ONE launch (dm_conv2d_igemm_proj): a ConvBlock's
+    exit when the block changes the channel count. Backward: the two convolutions' own backward passes."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, pack, r1, r2, wr, br, packr):
+        h, r1 = as_nhwc(h), as_nhwc(r1)
+        r2 = as_nhwc(r2) if r2 is not None else None
+        B, C, H, W = h.shape
+        Cout = weight.shape[0]
+        Cr1, Cr2 = r1.shape[1], (r2.shape[1] if r2 is not None else 0)
+        w_fwd, _ = pack.get(weight)
+        wr_fwd, _ = packr.get(wr)
+        y = empty_nhwc(B, Cout, H, W, h.device)
+        b32 = f32c(bias.detach()) if bias is not None else None
+        br32 = f32c(br.detach()) if br is not None else None
+        d = _conv_desc(B, H, W, C, 0, Cout, 3, 3, 1, 1, 0, 0, H, W)
+        proj = ConvProj(r1.data_ptr(), _p(r2), wr_fwd.data_ptr(), _p(br32), Cr1, Cr2)
+        check(lib.dm_conv2d_igemm_proj(ctypes.byref(d), h.data_ptr(), None, w_fwd.data_ptr(), _p(b32), ctypes.byref(proj),
+                                       y.data_ptr(), _stream()))
+        ctx.save_for_backward(h, r1, r2, weight, wr)
+        ctx.params = (weight, bias, wr, br)
+        ctx.packs = (pack, packr)
+        ctx.dims = (B, C, Cout, Cr1, Cr2, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, r1, r2, weight, wr = ctx.saved_tensors
+        _, bias, _, br = ctx.params
+        pack, packr = ctx.packs
+        B, C, Cout, Cr1, Cr2, H, W = ctx.dims
+        need = ctx.needs_input_grad
+        # one launch of column sums over dy serves both biases (the two convolutions' outputs are the terms of one sum)
+        twin = br if (br is not None and bias is not None and need[7] and need[2]) else None
+        dh, _, dw, db, _ = _conv_backward(h, None, weight, (weight, bias), twin, None,
+                                          (1, 1, 0, pack, bias is not None, False, (B, C, 0, H, W, H, W, H, W)), dy,
+                                          (need[0], False, need[1], need[2], False))
+        dr1, dr2, dwr, dbr, _ = _conv_backward(r1, r2, wr, (wr, br), None, None,
+                                               (1, 0, 0, packr, br is not None and twin is None, False,
+                                                (B, Cr1, Cr2, H, W, H, W, H, W)), dy,
+                                               (need[4], need[5] and r2 is not None, need[6], need[7], False))
+        return dh, dw, db, None, dr1, dr2, dwr, dbr, None
+
+
+def conv2d_proj(h, weight, bias, pack, r1, r2, wr, br, packr):
+    """conv3x3(h) + bias + conv1x1(r1 | r2) + br in one launch where the layer allows it (dm_conv2d_proj_fusable);
+    returns None where it does not, and the caller runs the two convolutions one after the other."""
+    if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or not h.is_cuda:
+        return None
+    B, C, H, W = h.shape
+    d = _conv_desc(B, H, W, C, 0, weight.shape[0], 3, 3, 1, 1, 0, 0, H, W)
+    proj = ConvProj(None, None, None, None, r1.shape[1], r2.shape[1] if r2 is not None else 0)
+    if tuple(r1.shape[2:]) != (H, W) or not lib.dm_conv2d_proj_fusable(ctypes.byref(d), ctypes.byref(proj)):
+        return None
+    return _ConvProjFn.apply(h, weight, bias, pack, r1, r2, wr, br, packr)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -145,6 +145,13 @@ class ConvBlock(nn.Module):
         if isinstance(self.res_proj, nn.Identity):
             res = x if skip is None else torch.cat([x, skip], dim=1)
             return self.conv2(h, res=res)
+        # the 1x1 projection of the block's input rides in conv2's launch where the layer allows it (its input chunks
+        # are multiplied into the same output tile behind the 3x3 taps: the projected residual never goes to memory)
+        if self.conv2.stride[0] == 1 and self.res_proj.kernel_size == (1, 1):
+            y = ops.conv2d_proj(h, self.conv2.weight, self.conv2.bias, self.conv2._pack, x, skip, self.res_proj.weight,
+                                self.res_proj.bias, self.res_proj._pack)
+            if y is not None:
+                return y
         # res_proj's output and conv2's are the two terms of one sum: one launch of column sums over the block's
         # output gradient serves both biases
         twin = self.res_proj.bias if (self.res_proj.bias is not None and self.conv2.bias is not None) else None

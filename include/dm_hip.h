@@ -56,6 +56,7 @@ int dm_abi_version(void);
 /* Run-time switches (tuning and A/B measurements; results are the same to the documented tolerances either way):
  *   "conv_patch" (1)      3x3 stride-1 convolutions use the LDS-staged-patch kernel
  *   "conv_gn_fuse" (1)    dm_conv2d_gn_fusable may say yes (GroupNorm in the producing convolution's epilogue)
+ *   "conv_proj_fuse" (1)  dm_conv2d_proj_fusable may say yes (a 1x1 projection of a second input inside the 3x3 launch)
  *   "dgrad_subpixel" (1)  stride-2 data gradients run by output-pixel parity class
  *   "wgrad_row3" (1)      3x3 weight gradients share one staged input row among the 3 taps of a kernel row
  *   "wgrad_row9" (0)      ... or all nine taps per workgroup (1: >= 512 input channels, 3: also >= 256 on images of
@@ -110,6 +111,26 @@ int dm_conv2d_igemm_gn(const dm_conv_desc* d, const void* x1, const void* x2, co
                        const void* res, void* y, const struct dm_gn_desc* g, const float* gamma, const float* beta,
                        const float* scale_shift, const float* pre_add, void* y_norm, float* mean, float* rstd,
                        void* stream);
+
+/* A 3x3 / stride-1 convolution and a 1x1 convolution of a SECOND input of the same spatial size, summed, in ONE launch:
+ *   y = conv3x3(x1 | x2, w) + bias + conv1x1(p.x1 | p.x2, p.w) + p.bias
+ * which is a ConvBlock's exit, `conv2(h) + res_proj(x)` (modeling/blocks.py:42-45, 73-75), when the block changes the
+ * channel count: the projection's input chunks are multiplied into the same accumulator tile behind the 3x3 taps, so the
+ * projected residual is never written to memory and read back. p.x1 | p.x2: bf16 [B][Ho][Wo][C1 | C2] (x2 null when
+ * C2 == 0), p.w: bf16 [Cout][C1+C2], p.bias: fp32 [Cout] or null. dm_conv2d_proj_fusable tells whether the layer takes it
+ * (3x3 / stride 1 / pad 1 layers of the patch kernel, no fused upsampling, C1 and C2 multiples of 64);
+ * dm_conv2d_igemm_proj fails with DM_ERR_UNSUPPORTED when it does not. The gradients are those of the two convolutions
+ * (dm_conv2d_igemm transposed, dm_conv2d_wgrad), one by one. */
+typedef struct dm_conv_proj {
+  const void* x1;
+  const void* x2;
+  const void* w;
+  const float* bias;
+  int C1, C2;
+} dm_conv_proj;
+int dm_conv2d_proj_fusable(const dm_conv_desc* d, const dm_conv_proj* p);
+int dm_conv2d_igemm_proj(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                         const dm_conv_proj* p, void* y, void* stream);
 
 /* dw[n][tap][c] += sum_m dy[m][n] * X(m,tap)[c]; dw fp32 [Cout][KH*KW][C1+C2], ACCUMULATES.
  * ws: caller-provided scratch (16-byte aligned, at least dm_conv2d_wgrad_ws_bytes(d) bytes, contents irrelevant on

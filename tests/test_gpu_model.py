@@ -447,7 +447,8 @@ def test_full_size_fused_paths_agree_with_separate_launches():
         return out.detach().clone(), {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
 
     base_out, base = run()
-    variants = [("conv_gn_fuse", 0, 1), ("dgrad_subpixel", 0, 1), ("wgrad_row9", 2, 0), ("boxes", None, None)]
+    variants = [("conv_gn_fuse", 0, 1), ("conv_proj_fuse", 0, 1), ("dgrad_subpixel", 0, 1), ("wgrad_row9", 2, 0),
+                ("boxes", None, None)]
     for key, off, on in variants:
         if key == "boxes":
             ops.SKIP_BOXES = False
@@ -462,11 +463,11 @@ def test_full_size_fused_paths_agree_with_separate_launches():
                 lib.dm_config_set(key.encode(), on)
         # (a fused path rounds a few values per thousand to the other bf16 neighbour; forty random-init layers carry
         # such a perturbation to ~1e-2 of the output, the size of the difference to the fp32 reference itself)
-        assert rel_err(out, base_out) < (2e-2 if key in ("conv_gn_fuse", "boxes") else 2e-3), key
+        assert rel_err(out, base_out) < (2e-2 if key in ("conv_gn_fuse", "conv_proj_fuse", "boxes") else 2e-3), key
         assert grads.keys() == base.keys()
         errs = {k: rel_err(grads[k], base[k]) for k in base if float(base[k].norm()) > 1e-8}
         worst = max(errs, key=errs.get)
-        assert errs[worst] < (6e-2 if key in ("conv_gn_fuse", "boxes") else 2e-2), (key, worst, errs[worst])
+        assert errs[worst] < (6e-2 if key in ("conv_gn_fuse", "conv_proj_fuse", "boxes") else 2e-2), (key, worst, errs[worst])
         if key in ("dgrad_subpixel", "wgrad_row9"):     # same values, other summation order of fp32 partials only
             assert np.median(list(errs.values())) < 1e-3, key
 

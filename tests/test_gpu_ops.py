@@ -362,6 +362,69 @@ def _groupnorm_case(B, C1, C2, H, W, act, ss, pre):
         assert rel_err(pred_.grad, prer.grad) < 2e-4
 
 
+CONV_PROJ_CASES = [
+    # B, C (3x3 input = output channels of conv1), Cout, Cr1, Cr2, H, W
+    (2, 128, 128, 256, 128, 32, 32),      # up.2 block 0 of the CIFAR model: tiles of 8 rows inside an image
+    (3, 256, 256, 128, 0, 16, 16),        # down.1 block 0: one image per tile, single-source projection
+    (9, 512, 512, 256, 0, 8, 8),          # four images per tile, ragged last tile, 64-wide tiles
+    (5, 64, 192, 64, 64, 8, 8),           # Cout not a multiple of 128
+    (2, 128, 128, 64, 192, 28, 28),       # tiles straddle image boundaries at arbitrary rows
+]
+
+
+@pytest.mark.parametrize("B,C,Cout,Cr1,Cr2,H,W", CONV_PROJ_CASES)
+def test_conv3x3_with_fused_1x1_projection(B, C, Cout, Cr1, Cr2, H, W):
+    """modeling/blocks.py:73-75, `conv2(h) + res_proj(x)` as ONE launch (dm_conv2d_igemm_proj) against torch's two
+    convolutions in fp32 on the bf16-rounded operands, forward and every gradient; and bit for bit against the two
+    launches it replaces where no intermediate rounding separates them (the gradients)."""
+    from dm_hip import ops, lib
+    rs = np.random.RandomState(B * 100 + C + Cr1 + H)
+    h = q(rnd(rs, B, C, H, W))
+    r1 = q(rnd(rs, B, Cr1, H, W))
+    r2 = q(rnd(rs, B, Cr2, H, W)) if Cr2 else None
+    w = rnd(rs, Cout, C, 3, 3, scale=1.0 / np.sqrt(9 * C))
+    wr = rnd(rs, Cout, Cr1 + Cr2, 1, 1, scale=1.0 / np.sqrt(Cr1 + Cr2))
+    b, br = rnd(rs, Cout, scale=0.1), rnd(rs, Cout, scale=0.1)
+    leaves = [t.clone().requires_grad_(True) for t in (h, r1, q(w), b, q(wr), br)]
+    hr, r1r, wq, bq, wrq, brq = leaves
+    r2r = r2.clone().requires_grad_(True) if r2 is not None else None
+    rin = r1r if r2r is None else torch.cat([r1r, r2r], 1)
+    y_ref = F.conv2d(hr, wq, bq, padding=1) + F.conv2d(rin, wrq, brq)
+    gy = q(rnd(rs, *y_ref.shape))
+    y_ref.backward(gy)
+
+    d = dev()
+    mk = lambda t: t.to(d).requires_grad_(True) if t is not None else None  # noqa: E731
+
+    def run(fused):
+        lib.dm_config_set(b"conv_proj_fuse", int(fused))
+        hd, r1d, r2d, wd, bd, wrd, brd = mk(h), mk(r1), mk(r2), mk(w), mk(b), mk(wr), mk(br)
+        pack, packr = ops.WeightPack(), ops.WeightPack()
+        y = ops.conv2d_proj(hd, wd, bd, pack, r1d, r2d, wrd, brd, packr)
+        assert (y is not None) == fused
+        if y is None:
+            y = ops.conv2d(hd, wd, bd, pack, res=ops.conv2d(r1d, wrd, brd, packr, x2=r2d), pad=1)
+        y.backward(gy.to(d))
+        return y, [t.grad if t is not None else None for t in (hd, r1d, r2d, wd, bd, wrd, brd)]
+
+    y, grads = run(True)
+    y0, grads0 = run(False)
+    assert y.dtype == torch.bfloat16 and rel_err(y.float(), y_ref) < BF16_FWD
+    # (the separate form rounds the projected residual to bf16 before the sum: the fused result is the closer one)
+    assert rel_err(y0.float(), y_ref) < 1.5 * BF16_FWD and rel_err(y.float(), y_ref) <= rel_err(y0.float(), y_ref) * 1.05
+    refs = [hr.grad, r1r.grad, r2r.grad if r2r is not None else None, wq.grad, bq.grad, wrq.grad, brq.grad]
+    tols = [BF16_FWD, BF16_FWD, BF16_FWD, 2e-3, 1e-4, 2e-3, 1e-4]
+    for g1, g0, ref, tol in zip(grads, grads0, refs, tols):
+        if ref is None:
+            assert g1 is None
+            continue
+        assert rel_err(g1.float(), ref) < tol
+        assert torch.equal(g1, g0)                    # same kernels on the same dy either way
+    # shapes the kernel does not take fall back (and say so by returning None)
+    assert ops.conv2d_proj(mk(h), mk(w), mk(b), ops.WeightPack(), mk(q(rnd(rs, B, 72, H, W))), None,
+                           mk(rnd(rs, Cout, 72, 1, 1)), None, ops.WeightPack()) is None
+
+
 def test_parameter_used_twice_collects_both_gradient_terms():
     """One GroupNorm affine pair applied twice in a forward pass files two deferred sums for the same gradient buffers:
     the grouped ordered sum must add both (it runs items with overlapping outputs one after the other)."""
