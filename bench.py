@@ -165,7 +165,8 @@ class AbiTimer:
         try:
             st = torch.cuda.Stream()
             st.wait_stream(torch.cuda.current_stream())
-            g = torch.cuda.CUDAGraph()
+            from dm_hip import ops
+            g = ops.new_graph()
             with torch.cuda.stream(st):
                 with torch.cuda.graph(g, stream=st):
                     for _ in range(BURST):
@@ -470,7 +471,7 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             if not split:
                 with torch.cuda.stream(side):
-                    graph = torch.cuda.CUDAGraph()
+                    graph = ops.new_graph()
                     run()  # warm-up on the capture stream
                     torch.cuda.synchronize()
                     with torch.cuda.graph(graph, stream=side):
@@ -488,7 +489,7 @@ def main():
                 torch.cuda.current_stream().wait_stream(side)
                 loss_static = step.capture_segmented(x, cls, stream=side)
                 torch.cuda.current_stream().wait_stream(side)
-                g_upd = torch.cuda.CUDAGraph()
+                g_upd = ops.new_graph()
                 with torch.cuda.graph(g_upd, stream=side):
                     step.update()
                 graph = step.segments[0][0]

@@ -45,6 +45,22 @@ SIDE_TOUCHED = set()
 SIDE_KEEP = []
 
 
+# HIP graphs are never destroyed. ROCm 7.2: destroying an instantiated graph whose capture forked onto other streams
+# frees stream objects that the runtime's list of graph-launch streams still names, and the next launch of ANY graph
+# with forks reads them (a segmentation fault inside hipGraphLaunch once that memory has been reused;
+# `DM_DESTROY_GRAPHS=1 python tools/diag_seg.py ddim ddpm euler h3` reproduces it, profiles/r03_graph_destroy_segfault.md has the native call stack). Every graph
+# this package captures is created through new_graph(), which keeps it alive until the process ends; callers that
+# capture graphs of their own around these operators should do the same.
+_GRAPHS = []
+
+
+def new_graph():
+    g = torch.cuda.CUDAGraph()
+    if os.environ.get("DM_DESTROY_GRAPHS") != "1":   # (set only by the reproducer of the fault)
+        _GRAPHS.append(g)
+    return g
+
+
 class SumCollector:
     """Deferred ordered sums (dm_sum_item): the producers of parameter-gradient partials fill in one item each
     instead of launching their own sum, and flush() runs all of them in ONE launch. The partial buffers are kept
@@ -332,6 +348,19 @@ class WeightPack:
                                           self.w_fwd.data_ptr(), self.w_dgrad.data_ptr(), _stream()))
             self.key = key
         return self.w_fwd, self.w_dgrad
+
+
+def refresh_packs(module):
+    """Bring the packed bf16 copies of every layer's weight up to date on the current stream (what a layer's next eager
+    call would do): for callers about to replay a HIP graph that was captured while the copies were current - the graph
+    reads the copies' buffers and holds no packing launch of its own. Returns the buffers' addresses (they stay where
+    they are unless a layer's weight changes size or a bound mirror is dropped: a graph is good for one such tuple)."""
+    where = []
+    for m in module.modules():
+        pack, w = getattr(m, "_pack", None), getattr(m, "weight", None)
+        if isinstance(pack, WeightPack) and w is not None and w.is_cuda:
+            where.append(pack.get(w)[0].data_ptr())
+    return tuple(where)
 
 
 def _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, transposed, Ho, Wo):

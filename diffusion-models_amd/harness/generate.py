@@ -10,6 +10,7 @@ except for the contents of z and t, so it is captured ONCE per (batch size, guid
 together with the sampler's update kernel (its per-step scalars come from a device table indexed by a device step
 counter, which also writes the next step's t) and, for DDPM, the noise draw: a sampler step is ONE graph launch.
 """
+import weakref
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
@@ -33,6 +34,10 @@ def make_generation_seed(dataset: str, n_examples: int, seed: Optional[int] = No
     else:
         cls = torch.arange(n_examples) % n_classes
     return {"z": z, "cls": cls}
+
+
+# model -> {(batch, labels?, guidance, chains, addresses of everything a graph reads): (label buffer, GraphedPredictor)}
+_CAPTURED = weakref.WeakKeyDictionary()
 
 
 class GraphedPredictor:
@@ -62,7 +67,8 @@ class GraphedPredictor:
             for _ in range(self.warmup):  # packs weights, sizes workspaces
                 self.pred_fn(self.z, self.t)
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
+        from dm_hip import ops
+        self.graph = ops.new_graph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = self.pred_fn(self.z, self.t)
 
@@ -84,7 +90,7 @@ class GraphedPredictor:
             for _ in range(self.warmup):  # packs weights, primes the allocator
                 self.pred_fn(L["z"], L["t"])
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
+        graph = ops.new_graph()
         if noisy:
             graph.register_generator_state(L["gen"])
         with torch.cuda.graph(graph), torch.no_grad():
@@ -194,23 +200,34 @@ def generate(model, sampler, scheduler, z: torch.Tensor, cls: Optional[torch.Ten
     was_training = model.training
     model.eval()
     sampler_kwargs = sampler_kwargs or {}
-    graphed: Dict[Tuple, GraphedPredictor] = {}
+    # Captured predictors (and the label buffers their graphs read) live with the model and serve every later call:
+    # graphs are never destroyed (dm_hip.ops.new_graph), so one per call would pile up. A graph reads the parameters
+    # through the pointers it was captured with: the key names them all, and the packed bf16 copies that a graph reads
+    # in place of a weight are brought up to date here, outside the graph.
+    cache = _CAPTURED.setdefault(model, {})
+    where = None
+    if use_graph:
+        from dm_hip import ops
+        where = tuple(t.data_ptr() for t in list(model.parameters()) + list(model.buffers())) + ops.refresh_packs(model)
     cond_buf: Dict[int, torch.Tensor] = {}
     outs = []
     for b0 in range(lo, hi, batch_size):
         b1 = min(hi, b0 + batch_size)
         zb = z[b0:b1].to(device)
         cond = None
-        if cls is not None:
-            # one persistent label buffer per batch size: a captured graph keeps reading it
-            cond = cond_buf.setdefault(b1 - b0, torch.empty(b1 - b0, dtype=torch.int64, device=device))
-            cond.copy_(cls[b0:b1])
         if use_graph:
-            key = (b1 - b0, cond is not None)
-            if key not in graphed:
-                graphed[key] = GraphedPredictor(interleaved_pred_fn(model, cond, guidance_scale, chains))
-            pred_fn = graphed[key]
+            key = (b1 - b0, cls is not None, float(guidance_scale) if guidance_scale is not None else None, chains, where)
+            if key not in cache:
+                # one persistent label buffer per captured predictor: its graph keeps reading it
+                cond = torch.empty(b1 - b0, dtype=torch.int64, device=device) if cls is not None else None
+                cache[key] = (cond, GraphedPredictor(interleaved_pred_fn(model, cond, guidance_scale, chains)))
+            cond, pred_fn = cache[key]
+            if cond is not None:
+                cond.copy_(cls[b0:b1])
         else:
+            if cls is not None:
+                cond = cond_buf.setdefault(b1 - b0, torch.empty(b1 - b0, dtype=torch.int64, device=device))
+                cond.copy_(cls[b0:b1])
             pred_fn = interleaved_pred_fn(model, cond, guidance_scale, chains)
         samples = sampler.sample(zb, scheduler, pred_fn, **sampler_kwargs)
         outs.append(torch.clip(samples, -1, 1).cpu())

@@ -294,7 +294,7 @@ class TrainStep:
             self._sums.flush()
             seg["graphs"][-1].capture_end()
             seg["after"].append([b])
-            g = torch.cuda.CUDAGraph()
+            g = ops.new_graph()
             g.capture_begin(pool=seg["pool"], capture_error_mode="relaxed")
             seg["graphs"].append(g)
             # auxiliary streams go on into the new capture: operators queued on them later (autograd keeps a branch
@@ -322,7 +322,7 @@ class TrainStep:
         with torch.cuda.stream(stream):
             # (relaxed mode: autograd runs backward on its own thread, so a capture begun on this one is ended
             # on that one at the first cut, and the last one the other way round)
-            g = torch.cuda.CUDAGraph()
+            g = ops.new_graph()
             g.capture_begin(pool=seg["pool"], capture_error_mode="relaxed")
             seg["graphs"].append(g)
             try:

@@ -25,6 +25,7 @@ class ProjectedEmbeddings:
     def __init__(self, embedding: torch.Tensor, blocks):
         self._raw = embedding
         self._side = None
+        self._untouched = True
         blocks = [b for b in blocks if b.emb_proj is not None and is_silu(b.nonlinearity)]
         self._proj = {}
         for i in range(0, len(blocks), self.MAX_GROUP):
@@ -44,10 +45,14 @@ class ProjectedEmbeddings:
                 t.record_stream(cur)     # allocated on the other stream's pool, used on this one
             self._side = None
 
-    @property
-    def pending(self):
-        """Still being computed on another stream (nobody has joined it yet)."""
-        return self._side is not None
+    def first_use(self):
+        """True for the first consumer of a forward pass only. That block may have to wait for projections still being
+        computed on another stream, so it starts its convolution first and normalises in a launch of its own; it does
+        so whether or not the embedding path really runs on another stream, so that a pass gives the same bits either
+        way (the separate GroupNorm launch and the convolution's epilogue add a sample's statistics in different
+        orders)."""
+        first, self._untouched = self._untouched, False
+        return first
 
     @property
     def raw(self):
@@ -129,10 +134,10 @@ class ConvBlock(nn.Module):
             h = self._norm_act(self.norm1, x, x2=skip, box=box)
         # conv1's bias gradient is the sum of norm2's input gradient, which norm2's backward has at hand. Where conv1's
         # output tiles hold whole samples (small images), norm2 runs in conv1's epilogue; it needs the embedding's
-        # projection for that, so a block that would have to wait for a projection still being computed on another
-        # stream (the first one) starts its convolution first and normalises in a launch of its own.
+        # projection for that, so the first block of a pass, which may have to wait for projections still being computed
+        # on another stream, starts its convolution first and normalises in a launch of its own.
         silu = is_silu(self.nonlinearity)
-        if isinstance(embedding, ProjectedEmbeddings) and embedding.pending:
+        if isinstance(embedding, ProjectedEmbeddings) and embedding.first_use():
             h, done = self.conv1(h, bias_grad=False), None
             mix = self._embedding_mix(embedding)
         else:

@@ -110,7 +110,7 @@ def test_step_in_phases_equals_step():
         with torch.cuda.stream(side):
             c.forward_backward(x, cls); c.reduce(); c.update()
             torch.cuda.synchronize()
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            g1, g2 = ops.new_graph(), ops.new_graph()
             with torch.cuda.graph(g1, stream=side):
                 loss = c.forward_backward(x, cls)
             c.reduce()
@@ -157,14 +157,14 @@ def test_graph_replay_single_and_segmented_equals_eager():
                 s_.arena.grad.zero_()
                 torch.cuda.synchronize()
             if s_ is b:
-                g1 = torch.cuda.CUDAGraph()
+                g1 = ops.new_graph()
                 with torch.cuda.graph(g1, stream=side):
                     s_._backward(s_.loss_given_noise(*args), overlap=False)
                 fb = g1.replay
             else:
                 s_.capture_segmented(loss_fn=lambda: s_.loss_given_noise(*args), stream=side)
                 fb = s_.replay_segmented
-            g2 = torch.cuda.CUDAGraph()
+            g2 = ops.new_graph()
             with torch.cuda.graph(g2, stream=side):
                 s_.update()
             graphs[s_] = (fb, g2)

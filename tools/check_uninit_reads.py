@@ -24,7 +24,7 @@ for n, m in model.named_modules():
 def poison():
     junk = [torch.full((n,), float("nan"), device=dev) for n in (1 << 22, 1 << 20, 1 << 18, 1 << 16, 1 << 14, 1 << 12, 3000, 70000, 500000)]
     del junk
-for B, hw in ((2, 16), (5, 32)):
+for B, hw in ((1, 16), (2, 16), (1, 32), (5, 32)):
     x = torch.randn(B, 3, hw, hw, generator=g).to(dev); t = torch.full((B,), 500, device=dev)
     c = torch.randint(0, 10, (B,), generator=g).to(dev)
     outs.clear()
