@@ -38,13 +38,15 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
 def measured_conv_traffic():
-    """Average HBM-side bytes per forward/data-gradient conv launch, from profiles/r02_conv_traffic.json (rocprofv3
-    --pmc passes of this benchmark; counters cannot be read from inside the run). None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return round(json.load(f)["conv_fwd_dgrad_bytes_per_launch"])
+    """Average HBM-side bytes per forward/data-gradient conv launch, from the newest profiles/r*_conv_traffic.json
+    (rocprofv3 --pmc passes of this benchmark; counters cannot be read from inside the run) and that file's name.
+    (None, None) if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return round(json.load(f)["conv_fwd_dgrad_bytes_per_launch"]), "profiles/" + os.path.basename(files[-1])
 
 
 def load_cfg(name):
@@ -559,7 +561,7 @@ def main():
                 wg[k] += v
         if ig and ig["ms"] > 0:
             achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
-            traffic = measured_conv_traffic()
+            traffic, traffic_file = measured_conv_traffic()
             roof = {"bound": "mfma",
                     "kernel": "conv_patch_kernel<128,6> / conv_patch_kernel<64,7> / conv_igemm_kernel<128>: every "
                               "dm_conv2d_igemm / _gn / _proj launch of a step (forward + data gradient; "
@@ -569,7 +571,7 @@ def main():
                     "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "bytes/launch",
-                    "traffic_source": "profiles/r02_conv_traffic.json (rocprofv3 --pmc passes of this benchmark: "
+                    "traffic_source": f"{traffic_file} (rocprofv3 --pmc passes of this benchmark: "
                                       "2 x FETCH_SIZE + WRITE_SIZE; not measured by this run)" if traffic else None,
                     "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["launches"]),
                     "launches_per_step": ig["launches"], "ms_per_step": round(ig["ms"], 3),
