@@ -306,7 +306,8 @@ extern "C" int dm_conv2d_igemm_gn(const dm_conv_desc* d, const void* x1, const v
                                   const float* bias, const void* res, void* y, const dm_gn_desc* g, const float* gamma,
                                   const float* beta, const float* scale_shift, const float* pre_add, void* y_norm,
                                   float* mean, float* rstd, void* stream) {
-  DM_REQUIRE(g && gamma && beta && y_norm && mean && rstd, DM_ERR_ARG, "dm_conv2d_igemm_gn: null argument");
+  DM_REQUIRE(g && gamma && beta && y_norm, DM_ERR_ARG, "dm_conv2d_igemm_gn: null argument");
+  DM_REQUIRE((mean == nullptr) == (rstd == nullptr), DM_ERR_ARG, "dm_conv2d_igemm_gn: mean and rstd go together");
   DM_REQUIRE((g->has_ss != 0) == (scale_shift != nullptr) && (g->has_pre != 0) == (pre_add != nullptr), DM_ERR_ARG,
              "dm_conv2d_igemm_gn: scale_shift/pre_add pointers disagree with the descriptor");
   DM_REQUIRE(dm_conv2d_gn_fusable(d, g), DM_ERR_UNSUPPORTED,
@@ -319,7 +320,7 @@ static int conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, c
                         const void* res, void* y, void* stream, const dm_gn_desc* g, const float* gamma,
                         const float* beta, const float* ss, const float* pre, void* y_norm, float* mean,
                         float* rstd, const dm_conv_proj* proj) {
-  DM_REQUIRE(d && x1 && w && y, DM_ERR_ARG, "dm_conv2d_igemm: null argument");
+  DM_REQUIRE(d && x1 && w && (y || g), DM_ERR_ARG, "dm_conv2d_igemm: null argument");
   DM_REQUIRE(d->C1 > 0 && d->C1 % BK == 0 && d->C2 >= 0 && d->C2 % BK == 0, DM_ERR_SHAPE,
              "dm_conv2d_igemm: input channels (%d, %d) must be multiples of %d", d->C1, d->C2, BK);
   DM_REQUIRE((d->C2 == 0) == (x2 == nullptr), DM_ERR_ARG, "dm_conv2d_igemm: x2 and C2 disagree");

@@ -40,7 +40,8 @@ struct PatchArgs {
   int M, n_mtiles, n_ntiles;
   unsigned x1_bytes, x2_bytes, w_bytes;
   // optional GroupNorm(+scale/shift)(+SiLU) of the output in the epilogue (gn_y != null): the tile must hold whole
-  // samples (BM % gn_hw == 0) and whole groups (BN % gn_cg == 0)
+  // samples (BM % gn_hw == 0) and whole groups (BN % gn_cg == 0); y and gn_mean / gn_rstd may then be null (inference:
+  // only a backward pass reads the raw output and the statistics)
   const float* gn_gamma;
   const float* gn_beta;
   const float* gn_ss;     // [B][2 Cout] or null
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
   for (int it = 0; it < NIT; ++it) {
     const int row = row_of(it);
     keep[it] = finish_row(row, cch);
-    if (row < rows_valid) *(bf16x8_t*)(y + (size_t)(m0 + row) * a.Cout + n0 + cch * 8) = keep[it];
+    if (y && row < rows_valid) *(bf16x8_t*)(y + (size_t)(m0 + row) * a.Cout + n0 + cch * 8) = keep[it];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {   // statistics of what a separate kernel would read back: the rounded values
       const float f = (float)keep[it][j];
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
       if (a.gn_ss) { sc = 1.f + a.gn_ss[(size_t)b * 2 * a.Cout + cj]; sh = a.gn_ss[(size_t)b * 2 * a.Cout + a.Cout + cj]; }
       ka = sc * a.gn_gamma[cj] * r;
       kb = ka * (pv - mu) + sc * a.gn_beta[cj] + sh;
-      if (c % a.gn_cg == 0) {
+      if (c % a.gn_cg == 0 && a.gn_mean) {
         a.gn_mean[(size_t)b * a.gn_G + cj / a.gn_cg] = mu;
         a.gn_rstd[(size_t)b * a.gn_G + cj / a.gn_cg] = r;
       }

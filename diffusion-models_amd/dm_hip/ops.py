@@ -446,7 +446,7 @@ class _ConvFn(Function):
 
     @staticmethod
     def forward(ctx, x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad=True, bias_twin=None, norm=None,
-                box=None):
+                box=None, raw=True):
         _require_device(x1, "conv2d")
         x1 = as_nhwc(x1)
         x2 = as_nhwc(x2) if x2 is not None else None
@@ -461,10 +461,9 @@ class _ConvFn(Function):
         Ho = (Hi + 2 * pad - KH) // stride + 1
         Wo = (Wi + 2 * pad - KW) // stride + 1
         w_fwd, _ = pack.get(weight)
-        y = empty_nhwc(B, Cout, Ho, Wo, x1.device)
         b32 = f32c(bias.detach()) if bias is not None else None
         d = _conv_desc(B, Hs, Ws, C1, C2, Cout, KH, KW, stride, pad, ups, 0, Ho, Wo)
-        y_norm = mean = rstd = None
+        y = y_norm = mean = rstd = None
         if norm is not None:
             ss, pre = norm.scale_shift, norm.pre_add
             g = GnDesc(B, Ho * Wo, Cout, 0, norm.groups, norm.eps, int(norm.act), int(ss is not None),
@@ -479,15 +478,18 @@ class _ConvFn(Function):
             if pre32 is not None and tuple(pre32.shape) != (B, Cout):
                 raise RuntimeError(f"group_norm: pre_add must be [{B}, {Cout}], got {tuple(pre32.shape)}")
             y_norm = empty_nhwc(B, Cout, Ho, Wo, x1.device)
-            mean = torch.empty((B, norm.groups), dtype=torch.float32, device=x1.device)
-            rstd = torch.empty((B, norm.groups), dtype=torch.float32, device=x1.device)
+            if raw:   # the raw output and the statistics: what the backward pass will read
+                y = empty_nhwc(B, Cout, Ho, Wo, x1.device)
+                mean = torch.empty((B, norm.groups), dtype=torch.float32, device=x1.device)
+                rstd = torch.empty((B, norm.groups), dtype=torch.float32, device=x1.device)
             check(lib.dm_conv2d_igemm_gn(ctypes.byref(d), x1.data_ptr(), _p(x2), w_fwd.data_ptr(), _p(b32), _p(res),
-                                         y.data_ptr(), ctypes.byref(g), f32c(norm.gamma.detach()).data_ptr(),
+                                         _p(y), ctypes.byref(g), f32c(norm.gamma.detach()).data_ptr(),
                                          f32c(norm.beta.detach()).data_ptr(), _p(ss32), _p(pre32), y_norm.data_ptr(),
-                                         mean.data_ptr(), rstd.data_ptr(), _stream()))
-            ctx.mark_non_differentiable(y_norm, mean, rstd)
+                                         _p(mean), _p(rstd), _stream()))
+            ctx.mark_non_differentiable(*[t for t in (y_norm, mean, rstd) if t is not None])
             ctx.set_materialize_grads(False)    # (no zero tensors made for the gradients of those three)
         else:
+            y = empty_nhwc(B, Cout, Ho, Wo, x1.device)
             check(lib.dm_conv2d_igemm(ctypes.byref(d), x1.data_ptr(), _p(x2), w_fwd.data_ptr(), _p(b32), _p(res),
                                       y.data_ptr(), _stream()))
         ctx.save_for_backward(x1, x2, weight)
@@ -505,7 +507,7 @@ class _ConvFn(Function):
         x1, x2, weight = ctx.saved_tensors
         dx1, dx2, dw, db, dres = _conv_backward(x1, x2, weight, ctx.params, ctx.bias_twin, ctx.box, ctx.cfg, dy,
                                                 ctx.needs_input_grad[:5])
-        return dx1, dx2, dw, db, dres, None, None, None, None, None, None, None, None
+        return dx1, dx2, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
 def _conv_backward(x1, x2, weight, params, bias_twin, box, cfg, dy, needs):
@@ -608,10 +610,12 @@ def conv2d(x1, weight, bias, pack, x2=None, res=None, stride=1, pad=0, ups=0, bi
     norm: a FusedNorm describing the GroupNorm that consumes the output. The call then returns (y, done) where
     done is (y_norm, mean, rstd) from the convolution's epilogue, to be passed to group_norm_act as `precomputed`,
     or None when the layer does not qualify and the GroupNorm has to run as a launch of its own.
+    With gradients switched off (sampling) a fused launch writes neither y nor the statistics, which only a backward
+    pass reads: the call returns (None, (y_norm, None, None)).
     box: a GradBox made for x1 (grad_box): the gradient it holds at backward time is added to x1's gradient in the
     data-gradient kernel's epilogue."""
     y, y_norm, mean, rstd = _ConvFn.apply(x1, x2, weight, bias, res, stride, pad, ups, pack, bias_grad, bias_twin, norm,
-                                          box)
+                                          box, torch.is_grad_enabled())
     if norm is None:
         return y
     return y, ((y_norm, mean, rstd) if y_norm is not None else None)

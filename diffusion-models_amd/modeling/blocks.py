@@ -143,7 +143,10 @@ class ConvBlock(nn.Module):
         else:
             mix = self._embedding_mix(embedding)
             h, done = self.conv1(h, bias_grad=False, norm=self.norm2.fused(act=silu, **mix))
-        h = self._norm_act(self.norm2, h, upstream_bias=self.conv1.bias, precomputed=done, **mix)
+        if h is None:    # no gradients: the fused launch wrote the normalised tensor only
+            h = done[0] if silu else self.nonlinearity(done[0])
+        else:
+            h = self._norm_act(self.norm2, h, upstream_bias=self.conv1.bias, precomputed=done, **mix)
         if self.training and self.dropout.p > 0:
             h = self.dropout(h)
 

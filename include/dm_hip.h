@@ -104,6 +104,8 @@ int dm_conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, const
  * normalised, activated tensor come out of the convolution's epilogue; y (the raw output, which the backward pass
  * needs) is written as by dm_conv2d_igemm, y_norm / mean / rstd as by dm_groupnorm_act_fwd on y (statistics taken from
  * the bf16-rounded y, pre_add folded in as there). g describes the GroupNorm over y (C1 = Cout, C2 = 0).
+ * y may be null, and mean / rstd (both) as well: the raw output and the statistics are then not written - only a backward
+ * pass reads them, so a forward pass without gradients (sampling, diffusion/sampler.py:52) saves that traffic.
  * dm_conv2d_gn_fusable tells whether a layer qualifies; dm_conv2d_igemm_gn fails with DM_ERR_UNSUPPORTED when it does not. */
 struct dm_gn_desc;
 int dm_conv2d_gn_fusable(const dm_conv_desc* d, const struct dm_gn_desc* g);

@@ -568,15 +568,21 @@ def test_conv_groupnorm_epilogue_is_batch_independent(H, Cout):
     bias, gamma, beta = (0.1 * rnd(rs, Cout)).to(d), (1 + 0.2 * rnd(rs, Cout)).to(d), (0.2 * rnd(rs, Cout)).to(d)
     e = rnd(rs, B, Cout).to(d)
     pack = ops.WeightPack()
-    with torch.no_grad():
-        out = []
-        for n in (B, 3):
-            y, done = ops.conv2d(x[:n].contiguous(memory_format=torch.channels_last), w, bias, pack, pad=1,
-                                 norm=ops.FusedNorm(gamma, beta, 32, 1e-5, True, pre_add=e[:n].contiguous()))
-            assert done is not None
-            out.append((y, *done))
+    out = []
+    for n in (B, 3):
+        y, done = ops.conv2d(x[:n].contiguous(memory_format=torch.channels_last), w, bias, pack, pad=1,
+                             norm=ops.FusedNorm(gamma, beta, 32, 1e-5, True, pre_add=e[:n].contiguous()))
+        assert done is not None
+        out.append((y, *done))
     for big, small in zip(*out):
         assert torch.equal(big[:3], small)
+    # with gradients off the launch writes the normalised tensor only (nothing reads the raw output or the statistics
+    # without a backward pass): same bits
+    with torch.no_grad():
+        y, done = ops.conv2d(x[:3].contiguous(memory_format=torch.channels_last), w, bias, pack, pad=1,
+                             norm=ops.FusedNorm(gamma, beta, 32, 1e-5, True, pre_add=e[:3].contiguous()))
+    assert y is None and done[1] is None and done[2] is None
+    assert torch.equal(done[0], out[1][1])
 
 
 @pytest.mark.parametrize("early", ["norm_fork", "norm", "conv_s2"])
