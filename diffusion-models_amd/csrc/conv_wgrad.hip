@@ -23,6 +23,8 @@ extern int g_dm_use_wgrad3;
 extern int g_dm_use_wgrad9;
 extern int g_dm_wgrad_slab_overhead;
 extern int g_dm_wgrad_reduce_cap;
+extern int g_dm_timing_skip;
+extern int g_dm_timing_twice;
 
 namespace {
 
@@ -1097,8 +1099,10 @@ extern "C" size_t dm_conv2d_wgrad_ws_bytes(const dm_conv_desc* d) {
 
 template <int TCO, int TCI>
 static void launch_single_tap(const WgradArgs& a, const WgradPlan& p, dim3 grid, hipStream_t st) {
+  if (g_dm_timing_skip & 4) return;
   hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, 4, 2>), grid, dim3(512), 0, st, a);
   const int G = a.splitk >= 8 ? 4 : (a.splitk >= 4 ? 2 : 1);   // waves sharing a chunk: at least two slices each
+  if (g_dm_timing_skip & 2) return;
   hipLaunchKernelGGL((wgrad_reduce_kernel<TCO, TCI>), dim3(reduce_grid((long)p.per * (TCO * TCI / 256) * G)), dim3(256), 0, st, a, G);
 }
 
@@ -1147,13 +1151,23 @@ static int reduce_waves(int splitk) { return splitk >= 8 ? 4 : (splitk >= 4 ? 2 
 
 static void launch_layer(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   dim3 grid((a.n_blocks + 7) / 8 * 8);
+  if (g_dm_timing_twice & ((p.row3 || p.row9) ? 64 : 4)) {   // timing experiments only: the main kernel once more
+    if (p.row9) hipLaunchKernelGGL((conv_wgrad9_kernel<4>), grid, dim3(512), 0, st, a);
+    else if (p.row3) hipLaunchKernelGGL((conv_wgrad3_kernel<4>), grid, dim3(512), 0, st, a);
+    else if (p.wide_co && p.wide_ci) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4, 2>), grid, dim3(512), 0, st, a);
+  }
   if (p.row9) {
     hipLaunchKernelGGL((conv_wgrad9_kernel<4>), grid, dim3(512), 0, st, a);
     const int G = reduce_waves(a.splitk);
+    if (g_dm_timing_skip & 2) return;
     hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(reduce_grid((long)p.per * (SLAB9_FLOATS / 256) * G)), dim3(256), 0, st, a, G);
   } else if (p.row3) {
+    if (g_dm_timing_skip & 64) return;
     hipLaunchKernelGGL((conv_wgrad3_kernel<4>), grid, dim3(512), 0, st, a);
     const int G = reduce_waves(a.splitk);
+    if (g_dm_timing_skip & 2) return;
+    if (g_dm_timing_twice & 2)
+      hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(reduce_grid((long)p.per * (SLAB_FLOATS / 256) * G)), dim3(256), 0, st, a, G);
     hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(reduce_grid((long)p.per * (SLAB_FLOATS / 256) * G)), dim3(256), 0, st, a, G);
   } else if (p.wide_co && p.wide_ci) launch_single_tap<128, 128>(a, p, grid, st);
   else if (p.wide_co) launch_single_tap<128, 64>(a, p, grid, st);

@@ -26,6 +26,15 @@ int g_dm_conv_gn_fuse = 1;            // GroupNorm(+SiLU) that follows a 3x3 con
 int g_dm_conv_proj_fuse = 1;          // a ConvBlock's 1x1 residual projection inside its second 3x3 convolution's launch
 int g_dm_edge_mfma = 1;               // UNet edge convs (image <-> features): matrix-core kernels instead of the VALU ones
 int g_dm_attn_mfma = 1;              // head dims 8 / 16: attention core on the matrix cores
+// TIMING EXPERIMENTS ONLY (results are wrong while set): a bit mask of launches that return at once without running,
+// to measure what a family of kernels costs the step end to end (what an infinitely fast replacement would buy):
+// 1: 1x1 convolutions (forward / data gradient), 2: the weight gradients' slab-sum kernels, 4: single-tap weight
+// gradients (1x1, stride 2), 8: GroupNorm backward, 16: GroupNorm forward, 32: stride-2 convolutions (forward / data
+// gradient), 64: three-tap weight gradients, 128: 3x3 stride-1 convolutions (forward / data gradient)
+int g_dm_timing_skip = 0;
+// The same families, launched TWICE (same bits; the results stay valid except that weight gradients whose slab sums
+// run twice come out doubled): the step's extra time is what the family costs end to end, on real data.
+int g_dm_timing_twice = 0;
 int g_dm_gn_bwd16 = 1;               // 513..1024-pixel GroupNorm backward: 512 threads x 16 pixels (no spills) instead of 1024 x 8
 
 namespace {
@@ -37,6 +46,7 @@ const Switch kSwitches[] = {
   {"gn_fused", &g_dm_gn_fused, 1},               {"conv_gn_fuse", &g_dm_conv_gn_fuse, 1},
   {"wgrad_row9", &g_dm_use_wgrad9, 0},           {"dgrad_subpixel", &g_dm_dgrad_subpixel, 1},
   {"edge_mfma", &g_dm_edge_mfma, 1},             {"attn_mfma", &g_dm_attn_mfma, 1},
+  {"timing_skip", &g_dm_timing_skip, 0},         {"timing_twice", &g_dm_timing_twice, 0},
   {"gn_bwd16", &g_dm_gn_bwd16, 1},               {"conv_proj_fuse", &g_dm_conv_proj_fuse, 1},
 };
 const Switch* find_switch(const char* key) {

@@ -64,6 +64,11 @@ int dm_abi_version(void);
  *   "wgrad_slab_overhead" (12), "wgrad_reduce_cap" (8192)   split-K planning of the weight-gradient kernels
  *   "gn_fused" (1), "gn_bwd16" (1)   single-pass GroupNorm kernels; 512 x 16-pixel form of the 1024-pixel backward
  *   "attn_mfma" (1), "edge_mfma" (1) matrix-core attention (head dims 8, 16) and edge convolutions
+ *   "timing_skip" (0)     TIMING EXPERIMENTS ONLY, results are wrong while non-zero: bit mask of kernel families whose
+ *                         launches return without running (1: 1x1 convolutions, 2: weight-gradient slab sums, 4:
+ *                         single-tap weight gradients, 8 / 16: GroupNorm backward / forward, 32: stride-2 convolutions,
+ *                         64: three-tap weight gradients, 128: 3x3 stride-1 convolutions), to measure what a family
+ *                         costs the step end to end
  * Unknown keys fail with DM_ERR_ARG. */
 int dm_config_set(const char* key, int value);
 int dm_config_get(const char* key, int* value);
