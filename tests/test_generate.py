@@ -98,3 +98,37 @@ def test_generate_graph_replay_equals_eager(sampler_name, kwargs):
     for chains, use_graph in ((2, True), (2, False), (3, True)):
         again = generate(model, sampler, sched, z, cls, batch_size=2, use_graph=use_graph, chains=chains)
         assert torch.equal(eager, again), (chains, use_graph)
+
+
+@pytest.mark.gpu
+def test_generate_reuses_its_graphs_and_follows_the_weights():
+    """generate() keeps the predictors it captured with the model (graphs are never destroyed, so they must not pile
+    up): a second call replays the same graphs, and after the parameters have been rewritten in place (a training step,
+    load_state_dict) the replayed graphs read the new weights - the packed bf16 copies are brought up to date outside
+    the graph - and give the images of the eager loop bit for bit."""
+    from diffusion.sampler import get_sampler
+    from diffusion.scheduler import get_scheduler
+    from dm_hip import ops
+    from harness import generate as G
+    from modeling import get_model
+    dev = torch.device("cuda:0")
+    model = get_model("unet", **TINY_CFG)
+    model.load_state_dict(det_sd_for(model, 5))
+    model = model.to(dev)
+    sched = get_scheduler("beta", n_steps=1000)
+    sampler = get_sampler("ddim", n_steps=3)
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(4, TINY_CFG["in_channels"], 16, 16, generator=g)
+    cls = torch.randint(0, 10, (4,), generator=g)
+    first = G.generate(model, sampler, sched, z, cls, batch_size=4)
+    n_graphs, n_cached = len(ops._GRAPHS), len(G._CAPTURED[model])
+    again = G.generate(model, sampler, sched, z, cls.flip(0), batch_size=4)        # other labels, same graphs
+    assert len(ops._GRAPHS) == n_graphs and len(G._CAPTURED[model]) == n_cached
+    assert torch.equal(again, G.generate(model, sampler, sched, z, cls.flip(0), batch_size=4, use_graph=False))
+    assert not torch.equal(again, first)
+    with torch.no_grad():
+        model.load_state_dict(det_sd_for(model, 6))                                 # in place: same addresses
+    third = G.generate(model, sampler, sched, z, cls, batch_size=4)
+    assert len(ops._GRAPHS) == n_graphs
+    assert torch.equal(third, G.generate(model, sampler, sched, z, cls, batch_size=4, use_graph=False))
+    assert not torch.equal(third, first)
