@@ -1,15 +1,15 @@
 """Bucketed gradient all-reduce over a flat gradient arena, overlapped with backward.
 
-The gradient arena is one contiguous fp32 buffer holding every parameter's gradient at a fixed offset
-(registration order). It is cut into contiguous buckets walking the parameters in REVERSE registration order -
-roughly the order in which backward produces them - and a bucket's all-reduce is launched the moment every
-parameter inside it has reported its gradient, while backward is still running on the remaining layers.
+The gradient arena is one contiguous fp32 buffer holding every parameter's gradient at a fixed offset (registration
+order, except that the parameters whose gradients appear last whatever their place - the embedding path - sit at its
+front: harness.train_step.arena_layout). It is cut into contiguous buckets from its END to its start - the order in
+which backward produces gradients - and a bucket's all-reduce is launched the moment every parameter inside it has
+reported its gradient, while backward is still running on the remaining layers.
 On MI355X nodes the backend is RCCL over xGMI ("nccl" in torch.distributed); the same code runs over gloo on
 CPU tensors, which is how the multi-process tests exercise it.
 """
 from typing import List, Sequence, Tuple
 
-import datetime
 import os
 import sys
 import time
