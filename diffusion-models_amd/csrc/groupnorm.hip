@@ -362,6 +362,15 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(GnArgs a) {
 // one wave holding eight) and the loads of a whole slab are in flight at once.
 // Groups never straddle the slab, so the group statistics are workgroup-local; all sums run in a fixed order.
 
+// Barrier for data handed over through LDS only. __syncthreads() also drains every outstanding global load and STORE
+// of the wave (vmcnt(0)); in the single-pass kernels, whose workgroups live for one latency chain, each such drain
+// behind a store of statistics or parameter partials is a memory round trip added to the chain.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // sums of NV per-thread 8-vectors over all pixel lanes: shuffles inside a wave (lanes with equal tid & 7), then a
 // fixed-order sum over the waves through LDS. Result for channel cc (0..63), quantity k in out[k * 64 + cc].
 template <int NV>
@@ -383,13 +392,13 @@ __device__ __forceinline__ void slab_block_sum(float (&part)[NV][8], float* red 
 #pragma unroll
       for (int j = 0; j < 8; ++j) red[(wave * NV + k) * 64 + lane * 8 + j] = part[k][j];
   }
-  __syncthreads();
+  lds_barrier();
   for (int i = threadIdx.x; i < NV * 64; i += blockDim.x) {
     float t = 0.f;
     for (int w = 0; w < nw; ++w) t += red[w * NV * 64 + i];
     out[i] = t;
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // element j (0..7) of 8 packed bf16 held as 4 words: a shift or a mask, no conversion instruction; holding the slab
@@ -437,13 +446,13 @@ __device__ __forceinline__ void slab_half_to_lds(float (&ph)[NV][4], float* red 
 template <int NV>
 __device__ __forceinline__ void slab_sum_finish(const float* red, float* out) {
   const int nw = blockDim.x >> 6;
-  __syncthreads();
+  lds_barrier();
   for (int i = threadIdx.x; i < NV * 64; i += blockDim.x) {
     float t = 0.f;
     for (int w = 0; w < nw; ++w) t += red[w * NV * 64 + i];
     out[i] = t;
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 template <int PPT, int MAXT, bool ACT>
@@ -451,7 +460,7 @@ __global__ __launch_bounds__(MAXT) void gn_fwd_fused_kernel(GnArgs a) {
   __shared__ float red[(MAXT / 64) * 2 * 64];
   __shared__ float sums[2 * 64];
   __shared__ float s_mean[64], s_rstd[64];   // per group of the slab
-  __shared__ float s_ka[64], s_kb[64];
+  __shared__ float s_ka[64], s_kb[64], s_pre[64];
   const int b = blockIdx.y, c0 = blockIdx.x * a.sw;
   const int v = threadIdx.x & 7, pl = threadIdx.x >> 3, PLN = blockDim.x >> 3;
   const int c = c0 + 8 * v;
@@ -463,6 +472,19 @@ __global__ __launch_bounds__(MAXT) void gn_fwd_fused_kernel(GnArgs a) {
   for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
 #pragma unroll
   for (int i = 0; i < PPT; ++i) xr[i] = load_slab_x(a, base, pl + i * PLN, c, cok);
+  // this thread's channel constants (threads 0..63: one channel of the slab each), fetched beside the slab instead of
+  // behind the reduction
+  float c_gamma = 0.f, c_beta = 0.f, c_sc = 1.f, c_sh = 0.f, c_pre = 0.f;
+  if (threadIdx.x < 64) {
+    const int cj = c0 + (int)threadIdx.x;
+    if ((int)threadIdx.x < a.sw && cj < a.C) {
+      c_gamma = a.gamma[cj];
+      c_beta = a.beta[cj];
+      if (a.ss) { c_sc = 1.f + a.ss[(size_t)b * 2 * a.C + cj]; c_sh = a.ss[(size_t)b * 2 * a.C + a.C + cj]; }
+      if (a.pre) c_pre = a.pre[(size_t)b * a.C + cj];
+    }
+    s_pre[threadIdx.x] = c_pre;   // (read behind the barriers of the block sum)
+  }
 #pragma unroll
   for (int i = 0; i < PPT; ++i)
 #pragma unroll
@@ -480,7 +502,7 @@ __global__ __launch_bounds__(MAXT) void gn_fwd_fused_kernel(GnArgs a) {
         const int cc = gl * a.cg + j;
         float u1 = sums[cc], u2 = sums[64 + cc];
         if (a.pre) {
-          const float pv = a.pre[(size_t)b * a.C + c0 + cc];
+          const float pv = s_pre[cc];
           u2 += 2.f * pv * u1 + (float)a.HW * pv * pv;
           u1 += (float)a.HW * pv;
         }
@@ -497,24 +519,21 @@ __global__ __launch_bounds__(MAXT) void gn_fwd_fused_kernel(GnArgs a) {
       a.rstd[(size_t)b * a.G + g] = r;
     }
   }
-  __syncthreads();
+  lds_barrier();
   // per-channel affine of the slab, once per workgroup
-  for (int cc = threadIdx.x; cc < 64; cc += blockDim.x) {
-    const int cj = c0 + cc;
+  if (threadIdx.x < 64) {
+    const int cc = threadIdx.x, cj = c0 + cc;
     float ka = 0.f, kb = 0.f;
     if (cc < a.sw && cj < a.C) {
       const int gl = cc / a.cg;
       const float r = s_rstd[gl], mu = s_mean[gl];
-      float sc = 1.f, sh = 0.f;
-      if (a.ss) { sc = 1.f + a.ss[(size_t)b * 2 * a.C + cj]; sh = a.ss[(size_t)b * 2 * a.C + a.C + cj]; }
-      const float pv = a.pre ? a.pre[(size_t)b * a.C + cj] : 0.f;
-      ka = sc * a.gamma[cj] * r;
-      kb = ka * (pv - mu) + sc * a.beta[cj] + sh;
+      ka = c_sc * c_gamma * r;
+      kb = ka * (c_pre - mu) + c_sc * c_beta + c_sh;
     }
     s_ka[cc] = ka;
     s_kb[cc] = kb;
   }
-  __syncthreads();
+  lds_barrier();
   if (!cok) return;
   float ka[8], kb[8];
 #pragma unroll
@@ -567,6 +586,8 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
   __shared__ float s_A[64], s_B[64];       // per group of the slab
   __shared__ __attribute__((aligned(16))) float s_k[4][64];   // per channel: xhat = xa * x + xb, u = ua * x + ub
   __shared__ __attribute__((aligned(16))) float s_AB[2][64];  // per channel: A and B of its group
+  __shared__ float s_kg[64];               // per channel: gamma * (1 + scale)
+  __shared__ float s_c[4][64];             // per channel: 1 + scale, gamma, beta, rstd (for the parameter-side results)
   const int b = blockIdx.y, c0 = blockIdx.x * a.sw;
   const int v = threadIdx.x & 7, pl = threadIdx.x >> 3, PLN = blockDim.x >> 3;
   const int c = c0 + 8 * v;
@@ -591,8 +612,12 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { xr[i][k] = xv[k]; dr[i][k] = dv[k]; }
   }
-  for (int cc = threadIdx.x; cc < 64; cc += blockDim.x) {
-    const int cj = c0 + cc;
+  // threads 0..63 own one channel of the slab each: its constants are fetched here, beside the slab, and kept (in
+  // LDS: the 16-pixel variant has no register to spare) for the parameter-side results behind the reduction, which
+  // then need no second trip to memory
+  if (threadIdx.x < 64) {
+    float c_sc = 1.f, c_gamma = 0.f, c_beta = 0.f, c_r = 0.f;
+    const int cc = threadIdx.x, cj = c0 + cc;
     float kxa = 0.f, kxb = 0.f, kua = 0.f, kub = 0.f;
     if (cc < a.sw && cj < a.C) {
       const int g = cj / a.cg;
@@ -600,14 +625,17 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
       const float pv = a.pre ? a.pre[(size_t)b * a.C + cj] : 0.f;
       const float sc = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + cj] : 1.f;
       const float sh = a.ss ? a.ss[(size_t)b * 2 * a.C + a.C + cj] : 0.f;
+      c_sc = sc; c_gamma = a.gamma[cj]; c_beta = a.beta[cj]; c_r = r;
       kxa = r;
       kxb = (pv - mu) * r;
-      kua = sc * a.gamma[cj] * r;
-      kub = sc * (a.gamma[cj] * kxb + a.beta[cj]) + sh;
+      kua = sc * c_gamma * r;
+      kub = sc * (c_gamma * kxb + c_beta) + sh;
     }
     s_k[0][cc] = kxa; s_k[1][cc] = kxb; s_k[2][cc] = kua; s_k[3][cc] = kub;
+    s_kg[cc] = c_gamma * c_sc;
+    s_c[0][cc] = c_sc; s_c[1][cc] = c_gamma; s_c[2][cc] = c_beta; s_c[3][cc] = c_r;
   }
-  __syncthreads();   // constants visible
+  lds_barrier();   // constants visible (the slab's loads may still be in flight)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const f32x4_t xa = *(const f32x4_t*)&s_k[0][8 * v + 4 * h], xb = *(const f32x4_t*)&s_k[1][8 * v + 4 * h];
@@ -653,7 +681,7 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
     for (int j = 0; j < a.cg; ++j) {
       const int cc = gl * a.cg + j, cj = c0 + cc;
       if (cj < a.C) {
-        const float k = a.gamma[cj] * (a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + cj] : 1.f);
+        const float k = s_kg[cc];
         A += k * sums[cc];
         Bv += k * sums[64 + cc];
       }
@@ -661,32 +689,30 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
     s_A[gl] = A * inv_n;
     s_B[gl] = Bv * inv_n;
   }
-  __syncthreads();
+  lds_barrier();
   // parameter-side gradients of this slab's channels; A and B per channel for the second pass
-  for (int cc = threadIdx.x; cc < 64; cc += blockDim.x) {
-    const int cj = c0 + cc, gl = cc < a.sw ? cc / a.cg : 0;
+  if (threadIdx.x < 64) {
+    const int cc = threadIdx.x, cj = c0 + cc, gl = cc < a.sw ? cc / a.cg : 0;
     s_AB[0][cc] = s_A[gl];
     s_AB[1][cc] = s_B[gl];
     if (cc < a.sw && cj < a.C) {
       const float av = sums[cc], bv = sums[64 + cc], xs = sums[128 + cc];
-      const float sc = a.ss ? 1.f + a.ss[(size_t)b * 2 * a.C + cj] : 1.f;
+      const float c_sc = s_c[0][cc], c_gamma = s_c[1][cc], c_beta = s_c[2][cc], c_r = s_c[3][cc];
       float* pp = a.pp + (size_t)b * 3 * a.C;
-      pp[cj] = sc * av;
-      pp[a.C + cj] = sc * bv;
+      pp[cj] = c_sc * av;
+      pp[a.C + cj] = c_sc * bv;
       if (a.dss) {
-        a.dss[(size_t)b * 2 * a.C + cj] = a.gamma[cj] * bv + a.beta[cj] * av;
+        a.dss[(size_t)b * 2 * a.C + cj] = c_gamma * bv + c_beta * av;
         a.dss[(size_t)b * 2 * a.C + a.C + cj] = av;
       }
       if (a.dpre || a.want_dup) {
-        const int g = cj / a.cg;
-        const float r = a.rstd[(size_t)b * a.G + g];
-        const float dxsum = r * (sc * a.gamma[cj] * av - (float)a.HW * s_A[gl] - s_B[gl] * xs);
+        const float dxsum = c_r * (c_sc * c_gamma * av - (float)a.HW * s_A[gl] - s_B[gl] * xs);
         if (a.dpre) a.dpre[(size_t)b * a.C + cj] = dxsum;
         if (a.want_dup) pp[2 * a.C + cj] = dxsum;
       }
     }
   }
-  __syncthreads();
+  lds_barrier();   // (the stores above are still on their way: nothing in this kernel reads them)
   if (!cok) return;
   // second pass: dx = ua * du - xa * (A + xhat * B) (+ dextra), pixel by pixel with all 8 channels' constants live
   // (no accumulators are left to hold), stored straight from the registers
