@@ -365,10 +365,14 @@ class TrainStep:
             self.reducer.begin()
             debug = os.environ.get("DM_DDP_DEBUG") == "2"   # (serialises: every graph is waited for before the next)
             for i, (g, buckets) in enumerate(zip(graphs, after)):
+                if debug:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 g.replay()
                 if debug:
+                    e1.record()
                     torch.cuda.synchronize()
-                    sys.stderr.write(f"[replay] graph {i} done\n")
+                    sys.stderr.write(f"[replay] graph {i}: {e0.elapsed_time(e1):.3f} ms, then buckets {buckets}\n")
                 for b in buckets:
                     self.reducer.launch(b)
             self.reducer.finish(plain=True)
