@@ -122,11 +122,18 @@ def load_latest_ckpt(step, ckpt_dir: str, dataset=None) -> dict:
     return ckpt
 
 
-def load_for_eval(run_dir: str, ckpt_name: str, use_ema: bool = True, sampling_steps: Optional[int] = None, device=None):
-    """save_fid_eval.py:126-142: (model, scheduler, sampler, config) of a checkpoint of a finished run."""
+def load_for_eval(run_dir: str, ckpt_name: str, use_ema: bool = True, sampling_steps: Optional[int] = None, device=None,
+                  model=None):
+    """save_fid_eval.py:126-142: (model, scheduler, sampler, config) of a checkpoint of a finished run.
+    model: the model a previous call returned for the same run. The checkpoint is then loaded INTO it (parameters keep
+    their addresses), so a loop over checkpoints (save_fid_eval.py:main_all_ckpt) goes on replaying the HIP graphs that
+    generate() captured for that model instead of capturing - and keeping alive - a new set per checkpoint."""
     with open(os.path.join(run_dir, "train_args.json")) as f:
         config = json.load(f)
-    model = get_model(config["model_type"], **config["model_cfg"])
+    if model is None:
+        model = get_model(config["model_type"], **config["model_cfg"])
+        if device is not None:
+            model.to(device)     # before loading: load_state_dict copies into the device tensors
     scheduler = get_scheduler(config["scheduler_type"], **config["scheduler_cfg"])
     sampler_cfg = dict(config["sampler_cfg"])
     if sampling_steps is not None:
@@ -136,8 +143,6 @@ def load_for_eval(run_dir: str, ckpt_name: str, use_ema: bool = True, sampling_s
     sd = torch.load(os.path.join(run_dir, "ckpts", ckpt_name, ckpt_file), weights_only=True)
     result = model.load_state_dict(sd)
     assert not result.missing_keys and not result.unexpected_keys, result
-    if device is not None:
-        model.to(device)
     model.eval()
     return model, scheduler, sampler, config
 

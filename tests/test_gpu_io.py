@@ -150,6 +150,19 @@ def test_run_directory_roundtrip_and_resume(tmp_path):
     assert all(torch.equal(v.cpu(), ema_sd[k]) for k, v in model.state_dict().items())
     imgs = generate(model, sampler, sched, torch.randn(3, 3, 16, 16, generator=g), torch.tensor([1, 2, 3]), batch_size=2)
     assert imgs.shape == (3, 3, 16, 16) and bool(torch.isfinite(imgs).all())
+    # the next checkpoint (here: the raw weights of the same one) loaded INTO that model: same object, same parameter
+    # addresses, so generate() goes on replaying the graphs it captured for it
+    from dm_hip import ops
+    n_graphs = len(ops._GRAPHS)
+    ptrs = [p.data_ptr() for p in model.parameters()]
+    model2, _, _, _ = C.load_for_eval(out, "ckpt-000003", use_ema=False, sampling_steps=3, device=dev(), model=model)
+    assert model2 is model and ptrs == [p.data_ptr() for p in model.parameters()]
+    raw_sd = torch.load(os.path.join(d, "model.pt"), weights_only=True)
+    assert all(torch.equal(v.cpu(), raw_sd[k]) for k, v in model.state_dict().items())
+    z3 = torch.randn(3, 3, 16, 16, generator=g)
+    imgs2 = generate(model, sampler, sched, z3, torch.tensor([1, 2, 3]), batch_size=2)
+    assert len(ops._GRAPHS) == n_graphs
+    assert torch.equal(imgs2, generate(model, sampler, sched, z3, torch.tensor([1, 2, 3]), batch_size=2, use_graph=False))
     with pytest.raises(RuntimeError):
         _step(use_ema=False).ema_state_dict()
 
