@@ -18,23 +18,32 @@ import torch
 import torch.distributed as dist
 
 
-def cut_buckets(offsets: Sequence[int], total: int, bucket_elems: int) -> List[Tuple[int, int]]:
+def cut_buckets(offsets: Sequence[int], total: int, bucket_elems: int, front: int = 0) -> List[Tuple[int, int]]:
     """[lo, hi) element ranges covering [0, total), boundaries on parameter offsets, each >= bucket_elems
-    (except possibly the one that starts at element 0), listed from the END of the arena to its start. `offsets` may
-    come in any order (a parameter's index need not follow its position in the arena)."""
+    (except possibly the last one or two), listed from the END of the arena to its start. `offsets` may come in any
+    order (a parameter's index need not follow its position in the arena).
+    front: [0, front) - the parameters whose gradients exist only when backward is over - is a bucket of its own, the
+    last one, whatever the bucket size: merged into the bucket behind it, it would hold that bucket's all-reduce back to
+    the end of backward as well."""
     offsets = sorted(offsets)
+    if front and front not in offsets:
+        raise ValueError(f"cut_buckets: front={front} is not a parameter boundary")
     buckets, hi = [], total
     for i in range(len(offsets) - 1, -1, -1):
         lo = offsets[i]
-        if hi - lo >= bucket_elems or i == 0:
+        if (hi - lo >= bucket_elems and lo >= front) or lo == front or i == 0:
             if hi > lo:
-                buckets.append((lo, hi))
+                if lo == front and front and hi - lo < bucket_elems and buckets:
+                    buckets[-1] = (lo, buckets[-1][1])     # a short run in front of the late region joins its neighbour
+                else:
+                    buckets.append((lo, hi))
             hi = lo
     return buckets
 
 
 class BucketedAllReduce:
-    def __init__(self, grad_arena: torch.Tensor, offsets: Sequence[int], bucket_bytes: int = 25 << 20, group=None):
+    def __init__(self, grad_arena: torch.Tensor, offsets: Sequence[int], bucket_bytes: int = 25 << 20, group=None,
+                 front: int = 0):
         self.grad = grad_arena
         self.group = group
         self.have_group = dist.is_available() and dist.is_initialized()
@@ -47,7 +56,7 @@ class BucketedAllReduce:
         # Optional callable(bucket index): called INSTEAD of launching the bucket's all-reduce when the bucket becomes
         # complete during backward (used to cut a HIP-graph capture there; the collective is issued at replay).
         self.on_bucket = None
-        self.buckets = cut_buckets(offsets, grad_arena.numel(), max(1, bucket_bytes // grad_arena.element_size()))
+        self.buckets = cut_buckets(offsets, grad_arena.numel(), max(1, bucket_bytes // grad_arena.element_size()), front)
         self.bucket_of, self.size = {}, [0] * len(self.buckets)
         for i, o in enumerate(offsets):
             for b, (lo, hi) in enumerate(self.buckets):

@@ -49,6 +49,14 @@ def arena_layout(names, numels, late=()):
     return offsets, off
 
 
+def late_region(names, offsets, late=()):
+    """Where the `late` parameters of arena_layout end: [0, that) holds them and nothing else (0: there are none, or
+    there is nothing behind them)."""
+    late = set(late)
+    rest = [o for n, o in zip(names, offsets) if n not in late]
+    return min(rest) if (rest and any(n in late for n in names)) else 0
+
+
 class FlatArena:
     """Parameters of a module re-homed into one contiguous fp32 buffer. self.params / names / shapes / offsets are in
     registration order (the order of state_dict() and of the optimizer state); the physical order is arena_layout's."""
@@ -60,6 +68,7 @@ class FlatArena:
         late_fn = getattr(module, "late_gradient_parameter_names", None)
         self.late = set(late_fn()) if late_fn is not None else set()
         self.offsets, off = arena_layout([n for n, _ in self.params], [p.numel() for _, p in self.params], self.late)
+        self.front = late_region([n for n, _ in self.params], self.offsets, self.late)   # end of the late region
         self.numel = off
         self.data = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
@@ -109,7 +118,8 @@ class TrainStep:
         self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
         self.steps = 0
         self._init_weight_mirrors()
-        self.reducer = BucketedAllReduce(self.arena.grad, self.arena.offsets, bucket_mb << 20, process_group)
+        self.reducer = BucketedAllReduce(self.arena.grad, self.arena.offsets, bucket_mb << 20, process_group,
+                                         front=self.arena.front)
         self.world = self.reducer.world
         if self.side_wgrad is None:
             self.side_wgrad = 1

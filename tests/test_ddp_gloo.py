@@ -67,7 +67,7 @@ def test_no_early_bucket_holds_an_embedding_path_parameter():
     import json
     sys.path.insert(0, PKG)
     from harness.ddp import cut_buckets
-    from harness.train_step import arena_layout
+    from harness.train_step import arena_layout, late_region
     from modeling import get_model
     with open(os.path.join(ROOT, "tests", "golden", "arg_json", "cos_cifar.json")) as f:
         cfg = json.load(f)
@@ -79,14 +79,15 @@ def test_no_early_bucket_holds_an_embedding_path_parameter():
     assert len(late) == 4 + 1 + 2 * 17 and late <= set(names)
     offsets, total = arena_layout(names, numels, late)
     assert sorted(offsets)[0] == 0 and len(set(offsets)) == len(offsets) and total >= sum(numels)
-    buckets = cut_buckets(offsets, total, (25 << 20) // 4)
-    assert len(buckets) >= 8
-    tail_lo, tail_hi = buckets[-1]
-    assert tail_lo == 0
-    for n, o in zip(names, offsets):
-        b = next(i for i, (lo, hi) in enumerate(buckets) if lo <= o < hi)
-        if n in late:
-            assert b == len(buckets) - 1, (n, b)
+    front = late_region(names, offsets, late)
+    assert 0 < front < (8 << 20) // 4
+    for mb in (1, 25, 50, 100, 1000):      # whatever the bucket size, the embedding path is the last bucket, alone
+        buckets = cut_buckets(offsets, total, (mb << 20) // 4, front)
+        assert buckets[-1] == (0, front) and (len(buckets) >= 8 or mb > 25)
+        assert buckets[0][1] == total and all(b[0] == a[1] for a, b in zip(buckets[1:], buckets))
+        for n, o in zip(names, offsets):
+            b = next(i for i, (lo, hi) in enumerate(buckets) if lo <= o < hi)
+            assert (b == len(buckets) - 1) == (n in late), (mb, n, b)
     # apart from the embedding path the physical order is the registration order: a bucket is a run of consecutive layers
     rest = [o for n, o in zip(names, offsets) if n not in late]
     assert rest == sorted(rest) and min(rest) > max(o for n, o in zip(names, offsets) if n in late)
