@@ -48,9 +48,9 @@ SIDE_KEEP = []
 # HIP graphs are never destroyed. ROCm 7.2: destroying an instantiated graph whose capture forked onto other streams
 # frees stream objects that the runtime's list of graph-launch streams still names, and the next launch of ANY graph
 # with forks reads them (a segmentation fault inside hipGraphLaunch once that memory has been reused;
-# `DM_DESTROY_GRAPHS=1 python tools/diag_seg.py ddim ddpm euler h3` reproduces it, profiles/r03_graph_destroy_segfault.md has the native call stack). Every graph
-# this package captures is created through new_graph(), which keeps it alive until the process ends; callers that
-# capture graphs of their own around these operators should do the same.
+# `DM_DESTROY_GRAPHS=1 python tools/diag_seg.py ddim ddpm euler h3` reproduces it and prints the native call stack).
+# Every graph this package captures is created through new_graph(), which keeps it alive until the process ends;
+# callers that capture graphs of their own around these operators should do the same.
 _GRAPHS = []
 
 

@@ -1,6 +1,6 @@
 """Deterministic weights shared by the golden-vector generator and the tests.
 
-The reference initialises with torch's default initialisers (SURVEY: modeling/unet.py:44-126 uses
+The reference initialises with torch's default initialisers (modeling/unet.py:44-126 uses
 plain nn.Conv2d / nn.Linear / nn.GroupNorm / nn.Embedding).  Golden vectors must not depend on torch's
 RNG stream, and multi-megabyte state dicts cannot be committed, so both sides rebuild the SAME weights
 from numpy's frozen legacy generator, walking the state dict in registration order.

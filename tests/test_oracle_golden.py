@@ -18,7 +18,7 @@ def test_schedules_bitexact():
     assert np.array_equal(O.beta_cosine(0.01, 0.9, 50).numpy(), g["cos_small_beta"])
     assert np.array_equal(O.rf_sigmas().numpy(), g["rf_sigmas"])
     assert np.array_equal(O.rf_sigmas(13).numpy(), g["rf_small_sigmas"])
-    # SURVEY known answers
+    # known answers probed from the reference (linear and cosine schedules)
     a = O.alpha_sq_from_beta(O.beta_linear())
     assert float(a[500]) == 0.07779665836502389 and float(a[999]) == 4.0358297653756754e-05
 
@@ -114,7 +114,7 @@ def test_losses_and_noising():
             assert np.array_equal(O.diffuse_vp(x, t, eps, tabs[k]).numpy(), g[f"xt_{k}"])
             loss = O.loss_vp(half, x, t, eps, tabs[k])
         assert float(loss) == float(g[f"loss_{k}"])
-    # SURVEY known answers
+    # known answers probed from the reference (linear and cosine schedules)
     assert abs(float(g["loss_lin"]) - 0.40292478) < 1e-7 and abs(float(g["loss_rf"]) - 1.79405022) < 1e-7
 
 
@@ -142,7 +142,7 @@ def test_samplers_bitexact():
     gen.manual_seed(7)
     out = O.sample_ddpm(z, O.beta_linear(), lin, 1000, pred, lambda i: torch.randn_like(z, generator=gen))
     assert _same(out, g["ddpm1000_lin_seed7"])
-    assert abs(float(out.double().sum()) - (-8037.306618)) < 1e-3  # SURVEY known answer
+    assert abs(float(out.double().sum()) - (-8037.306618)) < 1e-3  # known answer probed from the reference
 
 
 @pytest.mark.parametrize("fixture,kind", [("train_steps_tiny.npz", "vp"), ("train_steps_tiny_rf.npz", "rf")])

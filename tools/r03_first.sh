@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-3 first GPU call: DDP + harness tests, one bench line, then the two-rank full-size rehearsal over gloo
+# DDP + harness tests, one bench line, then the two-rank full-size rehearsal over gloo
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 600 python -u -m pytest tests/test_ddp_gpu.py tests/test_gpu_harness.py tests/test_zz_no_alloc.py "tests/test_gpu_ops.py::test_adamw_ema_step_matches_torch" "tests/test_gpu_model.py" -x -q --timeout 180 --timeout-method thread > gpurun_out/r03_t1.log 2>&1
