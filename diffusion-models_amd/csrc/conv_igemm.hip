@@ -264,6 +264,8 @@ int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, con
                       const void* res, void* y, hipStream_t st, const dm_gn_desc* g, const float* gamma,
                       const float* beta, const float* ss, const float* pre, void* y_norm, float* mean,
                       float* rstd, const dm_conv_proj* proj);
+int dm_conv1x1_try(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
+                   const void* res, void* y, hipStream_t st);
 int dm_conv_patch_gn_ok(const dm_conv_desc* d, const dm_gn_desc* g);
 int dm_conv_patch_proj_ok(const dm_conv_desc* d, const dm_conv_proj* p);
 extern int g_dm_use_patch_kernel;
@@ -371,6 +373,11 @@ static int conv2d_igemm(const dm_conv_desc* d, const void* x1, const void* x2, c
     return DM_OK;
   }
   DM_REQUIRE(!g && !proj, DM_ERR_UNSUPPORTED, "dm_conv2d_igemm_gn/_proj: layer not covered by the patch kernel");
+  // 1x1 stride-1 layers (and their data gradients) stream their activations past staged weights
+  if (dm_conv1x1_try(d, x1, x2, w, bias, res, y, (hipStream_t)stream) == DM_OK) {
+    DM_CHECK_LAUNCH();
+    return DM_OK;
+  }
 
   ConvArgs a;
   a.x1 = x1; a.x2 = x2; a.w = w; a.bias = bias; a.res = res; a.y = y;

@@ -82,6 +82,53 @@ def test_conv2d_fwd_bwd(B, C1, C2, Cout, H, W, k, stride, ups, patch):
         lib.dm_config_set(b"dgrad_subpixel", 1)
 
 
+@pytest.mark.parametrize("B,C1,C2,Cout,H,W,mode", [
+    (2, 128, 0, 256, 16, 16, 2),       # one chunk of input channels, two output tiles
+    (3, 128, 128, 128, 9, 11, 2),      # two sources (a chunk each), 297 pixels: a ragged last pixel tile
+    (1, 384, 128, 384, 8, 8, 2),       # four chunks through the two weight buffers, three output tiles
+    (32, 128, 0, 256, 32, 32, 1),      # the shape class the default takes (>= 32768 pixels, <= 256 input channels)
+    (2, 256, 0, 128, 16, 16, 1),       # ... and one it leaves to the gathered kernel (few pixels)
+])
+def test_conv1x1_streaming(B, C1, C2, Cout, H, W, mode):
+    """The streaming 1x1 kernel (activations from global memory straight into MFMA operands, transposed product,
+    output from registers) against the gathered kernel on the same operands - bias, residual, two sources - and
+    against torch fp32; forward and, through autograd, the data gradient (the same kernel on the transposed weights)."""
+    from dm_hip import lib, ops
+    rs = np.random.RandomState(B * 7 + Cout + H)
+    x1 = q(rnd(rs, B, C1, H, W))
+    x2 = q(rnd(rs, B, C2, H, W)) if C2 else None
+    w = q(rnd(rs, Cout, C1 + C2, 1, 1, scale=(C1 + C2) ** -0.5))
+    bias = 0.1 * rnd(rs, Cout)
+    res = q(rnd(rs, B, Cout, H, W))
+    gy = q(rnd(rs, B, Cout, H, W))
+    d = dev()
+
+    def run(stream):
+        lib.dm_config_set(b"conv1x1_stream", stream)
+        t1 = x1.to(d).to(torch.bfloat16).requires_grad_(True)
+        t2 = x2.to(d).to(torch.bfloat16).requires_grad_(True) if x2 is not None else None
+        wd = w.to(d).requires_grad_(True)
+        y = ops.conv2d(t1, wd, bias.to(d), ops.WeightPack(), x2=t2, res=res.to(d).to(torch.bfloat16))
+        y.backward(gy.to(d).to(torch.bfloat16))
+        torch.cuda.synchronize()
+        return y.detach().float(), t1.grad.float(), (t2.grad.float() if t2 is not None else None), wd.grad.clone()
+
+    ya, g1a, g2a, gwa = run(0)
+    yb, g1b, g2b, gwb = run(mode)
+    # same products, fp32 sums in another order: a few outputs fall to the other bf16 neighbour
+    for a_, b_ in ((ya, yb), (g1a, g1b)) + (((g2a, g2b),) if g2a is not None else ()):
+        diff = (a_ - b_).abs()
+        assert float(diff.max()) <= 2.0 ** -7 * max(1.0, float(a_.abs().max()))
+        assert float((diff > 0).float().mean()) < 2e-2
+    assert torch.equal(gwa, gwb)      # (the weight gradient does not go through this kernel)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = F.conv2d(xin, w, bias) + res
+    assert rel_err(yb.cpu(), ref) < BF16_FWD
+    gref = F.conv_transpose2d(gy, w)
+    gx = g1b if g2b is None else torch.cat([g1b, g2b], 1)
+    assert rel_err(gx.cpu(), gref) < BF16_FWD
+
+
 def _conv2d_case(B, C1, C2, Cout, H, W, k, stride, ups):
     from dm_hip import ops
     rs = np.random.RandomState(hash((B, C1, C2, Cout, H, W, k, stride, ups)) % (2 ** 31))

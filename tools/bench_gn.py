@@ -54,7 +54,7 @@ def main():
                                                             p(mean), p(rstd), p(ws), st)))
         def bwd(extra):
             return timeit(lambda: check(lib.dm_groupnorm_act_bwd(
-                ctypes.byref(d), p(x1), p(x2), p(g), p(b), p(ss), None, p(mean), p(rstd), p(dy), p(dex) if extra else None,
+                ctypes.byref(d), p(x1), p(x2), p(g), p(b), p(ss), None, p(mean), p(rstd), p(dy), p(dex) if extra else None, None,
                 p(dx1), p(dx2), p(dss), None, p(pp), 0, p(ws), st)))
         t_b, t_e = bwd(False), bwd(True)
         n = B * HW * C
