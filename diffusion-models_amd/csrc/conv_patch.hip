@@ -59,6 +59,7 @@ struct PatchArgs {
   const float* pbias;
   int PC1, PC2, PCin;
   unsigned p1_bytes, p2_bytes, pw_bytes;
+  int direct;   // plain output (no GroupNorm epilogue) straight from the accumulator registers
 };
 
 template <int BN, int NP>
@@ -163,10 +164,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
     gsrc[i] = ok ? ((b * a.Hs + (yin >> a.ups)) * a.Ws + (xin >> a.ups)) : -1;
     if (PROJ && ok && local >= 1 && local <= (k == 0 ? nrow0 : a.H)) own |= 1u << i;
   }
+  // Row r of a staged weight tile holds output channel n0 + chan_of_row(r): inside a wave's WN channels, row m of
+  // MFMA tile j is channel (j / 2) * 32 + (m / 4) * 8 + (j % 2) * 4 + m % 4. The product is formed transposed
+  // (weights as the MFMA's row operand), so accumulator register r of tile j in lane group fq is row 4 fq + r of
+  // that tile: with this deal a lane holds 8 CONSECUTIVE channels (tiles 2g, 2g + 1) of a pixel, and the output can
+  // leave the registers as 16-byte stores - 64 contiguous bytes per pixel and store instruction - without LDS.
+  auto chan_of_row = [](int r) {
+    const int base = r / WN * WN, lr = r - base, j = lr >> 4, m = lr & 15;
+    return base + (j >> 1) * 32 + (m >> 2) * 8 + (j & 1) * 4 + (m & 3);
+  };
   unsigned wrow[BP];
 #pragma unroll
   for (int i = 0; i < BP; ++i) {
-    const int n = n0 + (tid >> 3) + 64 * i;
+    const int n = n0 + chan_of_row((tid >> 3) + 64 * i);
     const int chunkB = (tid & 7) ^ ((tid >> 3) & 7);
     wrow[i] = (n < a.Cout) ? (unsigned)(n * 9 * a.Cin * 2 + chunkB * 16) : DM_OOB;
   }
@@ -236,8 +246,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[kk][i]),
-                                                              __builtin_bit_cast(bf16x8_t, bfr[kk][j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[kk][j]),
+                                                              __builtin_bit_cast(bf16x8_t, af[kk][i]), acc[i][j], 0, 0, 0);
     }
   };
   constexpr bool SHIFT = BN == 128;
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[i], b2[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[j], a2[i], acc[i][j], 0, 0, 0);
         }
       }
     };
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
     unsigned prow[BP];
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-      const int n = n0 + (tid >> 3) + 64 * i;
+      const int n = n0 + chan_of_row((tid >> 3) + 64 * i);
       const int chunkB = (tid & 7) ^ ((tid >> 3) & 7);
       prow[i] = (n < a.Cout) ? (unsigned)(n * a.PCin * 2 + chunkB * 16) : DM_OOB;
     }
@@ -391,8 +401,48 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
     }
   }
 
-  // ---- epilogue (the trailing dummy loads must have landed before LDS is reused)
+  // ---- epilogue (the trailing dummy loads must have landed before the workgroup ends or LDS is reused)
   wait_vmcnt<0>();
+  bf16_t* y = (bf16_t*)a.y;
+  const bf16_t* res = (const bf16_t*)a.res;
+  const int m0 = R0 * a.W;              // the tile's output pixels are contiguous in memory
+  const int rows_valid = min(a.TR * a.W, a.M - m0);
+  if (a.gn_y == nullptr && a.direct) {
+    // straight from the registers: lane (frow, fq) holds, of pixel wm * 64 + i * 16 + frow, the 8 channels
+    // n0 + wn * WN + g * 32 + fq * 8 .. of every g (accumulator tiles 2g and 2g + 1)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * 64 + i * 16 + frow;
+      if (row >= rows_valid) continue;
+#pragma unroll
+      for (int g = 0; g < NJ / 2; ++g) {
+        const int n = n0 + wn * WN + g * 32 + fq * 8;
+        if (n >= a.Cout) continue;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * g][r]; v[4 + r] = acc[i][2 * g + 1][r]; }
+        if (a.bias) {
+          const f32x4_t c0 = *(const f32x4_t*)(a.bias + n), c1 = *(const f32x4_t*)(a.bias + n + 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] += c0[r]; v[4 + r] += c1[r]; }
+        }
+        if (PROJ && a.pbias) {
+          const f32x4_t c0 = *(const f32x4_t*)(a.pbias + n), c1 = *(const f32x4_t*)(a.pbias + n + 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] += c0[r]; v[4 + r] += c1[r]; }
+        }
+        if (res) {
+          const bf16x8_t rv = *(const bf16x8_t*)(res + (size_t)(m0 + row) * a.Cout + n);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+        }
+        *(bf16x8_t*)(y + (size_t)(m0 + row) * a.Cout + n) = dm_pack8(v);
+      }
+    }
+    return;
+  }
+
+  // ---- with a GroupNorm epilogue the tile goes through LDS as [pixel][channel] floats first
   __syncthreads();
   float* ep = (float*)smem;
 #pragma unroll
@@ -401,13 +451,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        ep[(wm * 64 + i * 16 + fq * 4 + r) * L::EP_PITCH + wn * WN + j * 16 + frow] = acc[i][j][r];
+        ep[(wm * 64 + i * 16 + frow) * L::EP_PITCH + wn * WN + (j >> 1) * 32 + fq * 8 + (j & 1) * 4 + r] = acc[i][j][r];
   __syncthreads();
   constexpr int CPR = BN / 8;
-  bf16_t* y = (bf16_t*)a.y;
-  const bf16_t* res = (const bf16_t*)a.res;
-  const int m0 = R0 * a.W;              // the tile's output pixels are contiguous in memory
-  const int rows_valid = min(a.TR * a.W, a.M - m0);
   // 8 channels of one output row: accumulator + bias + residual, rounded to bf16
   auto finish_row = [&](int row, int cch) -> bf16x8_t {
     const float* src = ep + row * L::EP_PITCH + cch * 8;
@@ -431,7 +477,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_patch_kernel(PatchArgs a) {
     }
     return dm_pack8(v);
   };
-  if (a.gn_y == nullptr) {
+  if (a.gn_y == nullptr) {   // (patch_direct=0: the plain output through LDS as well, for comparison)
 #pragma unroll 2
     for (int it = 0; it < (BM * CPR) / NTHREADS; ++it) {
       const int item = tid + NTHREADS * it;
@@ -650,6 +696,8 @@ int dm_conv_patch_proj_ok(const dm_conv_desc* d, const dm_conv_proj* p) {
   return npix * p->C1 * 2 < 0x7fffffffL && npix * p->C2 * 2 < 0x7fffffffL && (long)d->Cout * (p->C1 + p->C2) * 2 < 0x7fffffffL;
 }
 
+extern int g_dm_patch_direct;
+
 int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, const void* w, const float* bias,
                       const void* res, void* y, hipStream_t st, const dm_gn_desc* g, const float* gamma,
                       const float* beta, const float* ss, const float* pre, void* y_norm, float* mean,
@@ -687,6 +735,7 @@ int dm_conv_patch_try(const dm_conv_desc* d, const void* x1, const void* x2, con
     a.p2_bytes = (unsigned)(M * proj->C2 * 2);
     a.pw_bytes = (unsigned)((long)d->Cout * a.PCin * 2);
   }
+  a.direct = g_dm_patch_direct;
   a.gn_y = nullptr;
   a.gn_gamma = a.gn_beta = a.gn_ss = a.gn_pre = nullptr;
   a.gn_mean = a.gn_rstd = nullptr;

@@ -108,6 +108,42 @@ def test_attention_layer_vs_reference(name):
     _check_param_grads(m, g, BLOCK_BWD)
 
 
+def test_attention_dropout(monkeypatch):
+    """Dropout on the attention weights (modeling/attention.py:75-78; no configuration trains with it). With the mask
+    switched off the path that materialises the weights equals the attention kernel to bf16 rounding, forward and
+    backward; with p = 0.5 it draws a fresh mask per call, keeps the expectation, and eval() ignores it."""
+    import torch.nn.functional as F
+    from modeling.attention import Attention2D
+    g = golden("layer_attn_8x8.npz")
+    c, d, B, H, W, seed = (int(v) for v in g["meta"])
+    plain = _load(Attention2D(c, n_dim_head=d, norm_groups=32), seed)
+    drop = _load(Attention2D(c, n_dim_head=d, norm_groups=32, dropout=0.5), seed)
+    assert float(drop.dropout_p) == 0.5 and set(drop.state_dict()) == set(plain.state_dict())
+    x = T(g["in_x"]).to(dev())
+    gy = T(g["gy"]).to(dev())
+
+    def run(m):
+        xi = x.clone().requires_grad_(True)
+        out = m(xi)
+        out.backward(gy)
+        return out.float(), xi.grad.float(), m.qkv_proj.weight.grad.float().clone()
+
+    ref = run(plain)
+    monkeypatch.setattr(F, "dropout", lambda w, p, training: w)
+    same = run(drop)
+    monkeypatch.undo()
+    for a, b in zip(same, ref):
+        assert rel_err(a, b) < 5e-3
+    outs = [run(drop)[0] for _ in range(64)]
+    assert not torch.equal(outs[0], outs[1])
+    # out = residual + out_proj(attention): the mean over masks approaches the output without dropout
+    assert rel_err(torch.stack(outs).mean(0), ref[0]) < 0.25 * rel_err(outs[0], ref[0])
+    drop.eval()
+    plain.eval()
+    with torch.no_grad():
+        assert torch.equal(drop(x), plain(x))
+
+
 def _unet(name, cfg):
     from modeling import get_model
     g = golden(f"unet_{name}.npz")
