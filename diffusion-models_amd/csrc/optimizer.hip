@@ -1,6 +1,6 @@
 // Optimizer tail on flat fp32 arenas: global gradient norm, and one fused pass for
 // clip -> AdamW (decoupled weight decay, bias correction) -> EMA -> bf16 weight copy.
-// HBM-bound: 4 B/param for the norm, 28 B/param (+12 EMA, +2 bf16) for the update.
+// HBM-bound: 4 B/param for the norm, 28 B/param (+8 EMA, +2 bf16, +4 gradient zeroing) for the update.
 #include "dm_common.h"
 
 namespace {
@@ -53,6 +53,8 @@ __global__ __launch_bounds__(NT) void adamw_ema_kernel(float* __restrict__ p, fl
   const float step_size = lr / bc1;
   const float sqrt_bc2 = sqrtf(bc2);
   const float omd = 1.f - ema_decay;
+  // (4-byte accesses on purpose: with five arenas read and five written per element, 16-byte accesses measured
+  // slower - 490-506 against 443-449 us for 55.9 M parameters, 4.2-4.3 against 4.7-4.8 TB/s)
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
     const float gi = g[i] * grad_scale * clip;
     if (ZERO) g[i] = 0.f;
