@@ -59,6 +59,8 @@ int dm_abi_version(void);
  *   "conv_proj_fuse" (1)  dm_conv2d_proj_fusable may say yes (a 1x1 projection of a second input inside the 3x3 launch)
  *   "conv1x1_stream" (1)  1x1 stride-1 convolutions with at most 256 input channels over >= 32768 pixels (channels in
  *                         multiples of 128) take the streaming kernel; 2: wherever the channel counts allow; 0: never
+ *   "patch_direct" (1)    plain outputs of the patch kernel leave the accumulator registers directly (0: through LDS,
+ *                         as the outputs with a GroupNorm epilogue always do); bit-identical either way
  *   "dgrad_subpixel" (1)  stride-2 data gradients run by output-pixel parity class
  *   "wgrad_row3" (1)      3x3 weight gradients share one staged input row among the 3 taps of a kernel row
  *   "wgrad_row9" (3)      ... or all nine taps per workgroup: 0 never, 1 from 512 input channels, 3 also from 256 input

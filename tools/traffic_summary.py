@@ -32,7 +32,7 @@ def main():
     print("| kernel | dispatches | FETCH_SIZE KB | read MB (x2) | write MB | total MB per launch |\n|---|---|---|---|---|---|")
     for r in rows[:28]:
         print(f"| `{r[0]}` | {r[1]} | {r[2]:.0f} | {r[3]:.1f} | {r[4]:.1f} | {r[5]:.1f} |")
-    conv = [r for r in rows if r[0].startswith(("void conv_patch_kernel", "void conv_igemm_kernel"))]
+    conv = [r for r in rows if r[0].startswith(("void conv_patch_kernel", "void conv_igemm_kernel", "conv1x1_kernel"))]
     launches = sum(r[1] for r in conv)
     out = {"conv_fwd_dgrad_bytes_per_launch": sum(r[5] * 1e6 * r[1] for r in conv) / max(launches, 1),
            "per_kernel_MB": {r[0]: {"dispatches": r[1], "read": round(r[3], 2), "write": round(r[4], 2)} for r in rows[:28]}}
