@@ -1020,12 +1020,18 @@ class _InConvFn(Function):
     def backward(ctx, dy):
         (x32,) = ctx.saved_tensors
         B, Cs, H, W, Cb, has_bias = ctx.cfg
-        if ctx.needs_input_grad[0]:
-            raise RuntimeError("in_conv: gradient w.r.t. the image is not implemented (the reference never needs it)")
         dy = as_nhwc(dy)
         weight, bias = ctx.params
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # (training never asks for it; guidance or inversion through the network does.) The data gradient of a 3x3
+            # 'same' convolution is the convolution of dy with the kernels flipped and the channel roles swapped: the
+            # features -> image kernel of the last layer
+            w_t = f32c(weight.detach().permute(1, 0, 2, 3).flip(2, 3))
+            dx = torch.empty(B, Cs, H, W, dtype=torch.float32, device=dy.device)
+            check(lib.dm_out_conv_fwd(dy.data_ptr(), w_t.data_ptr(), None, dx.data_ptr(), B, Cs, H, W, Cb, _stream()))
         dw, db = _edge_wgrad(x32, dy, weight, bias, (B, Cs, H, W, Cb), True, (x32, dy))
-        return None, dw, db
+        return dx, dw, db
 
 
 def _edge_wgrad(small, big, weight, bias, shape, big_is_output, wait_for):

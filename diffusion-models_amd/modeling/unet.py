@@ -97,6 +97,8 @@ class UNet(nn.Module, GuidedPredictor):
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, cls: Optional[torch.Tensor] = None,
                 uncond_mask: Optional[torch.Tensor] = None):
+        if x.shape[0] == 0:   # an empty batch (a ragged split's last shard): nothing to launch
+            return x.new_zeros((0, self.out_conv.out_channels) + tuple(x.shape[2:]))
         if x.is_cuda and ops.EMB_SIDE_STREAM:
             # the embedding path beside the first convolutions: its first consumer is the first block's second norm
             # (one auxiliary stream per calling stream: callers that run several sub-batches on streams of their own

@@ -108,6 +108,29 @@ def test_attention_layer_vs_reference(name):
     _check_param_grads(m, g, BLOCK_BWD)
 
 
+def test_unet_batch_of_one_image_gradient_and_empty_batch():
+    """Edge cases of UNet.forward (modeling/unet.py:129-163): a batch of one with the gradient w.r.t. the IMAGE (which
+    training never asks for) against the oracle, and an empty batch, which returns an empty tensor of the output's
+    shape without a launch."""
+    from oracle import unet_oracle as O
+    g, m = _unet("tiny", TINY_CFG)
+    x = T(g["x"])[:1]
+    t, cls = T(g["t"])[:1], T(g["cls"])[:1]
+    xd = x.to(dev()).requires_grad_(True)
+    out = m(xd, t.to(dev()), cls.to(dev()))
+    out.float().square().sum().backward()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    ref = O.unet_forward(sd, TINY_CFG, xr, t, cls)
+    ref.square().sum().backward()
+    assert rel_err(out.float(), ref.detach()) < 1e-2
+    e = rel_err(xd.grad, xr.grad)
+    print(f"image gradient rel-err {e:.3e}")
+    assert e < 5e-2
+    empty = m(xd[:0], t[:0].to(dev()), cls[:0].to(dev()))
+    assert tuple(empty.shape) == (0,) + tuple(out.shape[1:]) and empty.dtype == out.dtype
+
+
 def test_attention_dropout(monkeypatch):
     """Dropout on the attention weights (modeling/attention.py:75-78; no configuration trains with it). With the mask
     switched off the path that materialises the weights equals the attention kernel to bf16 rounding, forward and

@@ -782,14 +782,16 @@ def _edge_convs_case(B, Cs, H, W, Cb):
     d = dev()
     # image -> features
     x, w, b = rnd(rs, B, Cs, H, W), rnd(rs, Cb, Cs, 3, 3, scale=0.2), rnd(rs, Cb, scale=0.1)
-    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-    y_ref = F.conv2d(x, wr, br, padding=1)
+    wr, br, xr = w.clone().requires_grad_(True), b.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, br, padding=1)
     gy = q(rnd(rs, *y_ref.shape))
     y_ref.backward(gy)
-    wd, bd = w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
-    y = ops.in_conv(x.to(d), wd, bd)
+    wd, bd, xd = w.to(d).requires_grad_(True), b.to(d).requires_grad_(True), x.to(d).requires_grad_(True)
+    y = ops.in_conv(xd, wd, bd)
     assert rel_err(y.float(), y_ref) < 4e-3          # one bf16 rounding of the output
     y.backward(gy.to(d))
+    # the gradient w.r.t. the image (guidance / inversion through the network; training does not ask for it)
+    assert xd.grad.shape == x.shape and rel_err(xd.grad, xr.grad) < 1e-5
     # the weight gradient takes the image in bf16, as the reference's autocast conv does
     wq = w.clone().requires_grad_(True)
     F.conv2d(q(x), wq, None, padding=1).backward(gy)
