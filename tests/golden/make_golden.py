@@ -252,6 +252,13 @@ def dump_unets():
             gnone=m.get_pred_fn(cond=None, guidance_scale=3.0)(z, t))
 
 
+def dump_unet_activations():
+    """The block activations other than SiLU that get_activation offers (modeling/activation.py:4-12): ReLU with
+    scale/shift mixing, GELU with additive mixing and attention stages."""
+    unet_case("tiny_relu", dict(TINY_CFG, activation="relu"), 730, 2, 16, store_all_grads=False)
+    unet_case("tiny_gelu", dict(TINY_ATTN_CFG, activation="gelu"), 740, 2, 16, store_all_grads=False)
+
+
 # ----------------------------------------------------------------------------------------------
 # 4. scheduler losses + samplers with analytic models
 def dump_diffusion():
@@ -464,6 +471,8 @@ if __name__ == "__main__":
         dump_layers()
     if "unets" in which:
         dump_unets()
+    if "activations" in which:
+        dump_unet_activations()
     if "diffusion" in which:
         dump_diffusion()
     if "train" in which:

@@ -175,12 +175,17 @@ def _unet(name, cfg):
 
 
 @pytest.mark.parametrize("name,cfg", [("tiny", TINY_CFG), ("tiny_attnblocks", TINY_ATTN_CFG), ("fid_test", None),
-                                      ("rf_mnist", None), ("cos_cifar", None)])
+                                      ("rf_mnist", None), ("cos_cifar", None),
+                                      # block activations other than SiLU (modeling/activation.py:4-12): not fused into
+                                      # the GroupNorm kernels, applied as separate elementwise passes
+                                      ("tiny_relu", dict(TINY_CFG, activation="relu")),
+                                      ("tiny_gelu", dict(TINY_ATTN_CFG, activation="gelu"))])
 def test_unet_vs_reference(name, cfg):
     cfg = cfg or load_cfg(name)["model_cfg"]
     g, m = _unet(name, cfg)
     d = dev()
     x, t, cls, mask = (T(g[k]).to(d) for k in ("x", "t", "cls", "mask"))
+    x.requires_grad_(True)
     out = m(x, t, cls=cls, uncond_mask=mask)
     assert out.dtype == torch.float32 and tuple(out.shape) == tuple(g["out"].shape)
     assert rel_err(out, T(g["out"])) < NET_FWD
@@ -188,6 +193,13 @@ def test_unet_vs_reference(name, cfg):
         assert rel_err(m(x, t), T(g["out_nocls"])) < NET_FWD
         assert rel_err(m(x, t, cls=cls), T(g["out_nomask"])) < NET_FWD
     out.backward(T(g["gy"]).to(d))
+    # ReLU gates are discontinuous: of GroupNorm'd activations ~0.3 % lie within a bf16 rounding of zero and flip
+    # against the fp32 reference, which moves a gradient by sqrt(0.003) ~ 5 % of its norm per layer (the forward
+    # barely notices: those values are ~0 either way). Gradients of the ReLU network are held to 4x the tolerance.
+    loose = 4.0 if "relu" in name else 1.0
+    e_gx = rel_err(x.grad, T(g["gx"]))                # the gradient w.r.t. the image
+    print(f"{name}: image gradient rel-err {e_gx:.3e}")
+    assert e_gx < loose * NET_BWD
     names = [str(s) for s in g["grad_names"]]
     got = dict(m.named_parameters())
     worst = 0.0
@@ -197,11 +209,11 @@ def test_unet_vs_reference(name, cfg):
             assert gr is None or float(gr.float().norm()) < 1e-5, k
             continue
         n = float(gr.double().norm())
-        assert abs(n - ref_norm) < NET_BWD * ref_norm, (k, n, ref_norm)
+        assert abs(n - ref_norm) < loose * NET_BWD * ref_norm, (k, n, ref_norm)
         flat = gr.float().flatten().cpu()
         s = flat[:: max(1, flat.numel() // 16)][:16]
         ref = T(ref_s)[: s.numel()]
-        worst = max(worst, float((s - ref).norm() / max(float(ref_norm) / np.sqrt(flat.numel()) * 4, 1e-12)))
+        worst = max(worst, float((s - ref).norm() / max(float(ref_norm) / np.sqrt(flat.numel()) * 4 * loose, 1e-12)))
     assert worst < 1.0, worst   # sampled entries off by less than 4 rms-entries * tolerance scale
 
 
