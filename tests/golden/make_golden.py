@@ -252,6 +252,35 @@ def dump_unets():
             gnone=m.get_pred_fn(cond=None, guidance_scale=3.0)(z, t))
 
 
+def dump_stage_blocks():
+    """The stage classes no shipped configuration instantiates: the embedding-free Encoder / Decoder stages
+    (modeling/blocks.py:422-632) and a MidBlock without attention, as stand-alone modules."""
+    from modeling.blocks import get_down_block, get_up_block, MidBlock
+    rs = np.random.RandomState(4321)
+    cases = [
+        ("stage_enc_down", get_down_block("EncoderDownBlock", in_channels=64, out_channels=128, n_blocks=2, norm_groups=32,
+                                          activation="silu", dropout=0.0, downsample=True, downsample_use_conv=True),
+         (2, 64, 8, 8)),
+        ("stage_enc_attn_down", get_down_block("EncoderAttnDownBlock", in_channels=64, out_channels=64, n_blocks=1,
+                                               n_dim_head=8, norm_groups=32, activation="silu", dropout=0.0,
+                                               downsample=False), (2, 64, 8, 8)),
+        ("stage_dec_up", get_up_block("DecoderUpBlock", in_channels=128, out_channels=64, next_out_channels=None, n_blocks=2,
+                                      norm_groups=32, activation="silu", dropout=0.0, upsample=True,
+                                      upsample_use_conv=True), (2, 128, 4, 4)),
+        ("stage_dec_attn_up", get_up_block("DecoderAttnUpBlock", in_channels=64, out_channels=64, next_out_channels=None,
+                                           n_blocks=1, n_dim_head=16, norm_groups=32, activation="silu", dropout=0.0,
+                                           upsample=False), (2, 64, 8, 8)),
+        ("stage_mid_noattn", MidBlock(64, n_blocks=1, norm_groups=32, activation="silu", embedding_dim=None,
+                                      add_attention=False), (2, 64, 8, 8)),
+    ]
+    for i, (name, mod, shape) in enumerate(cases):
+        load_det_weights(mod, 800 + i)
+        mod.train()
+        r = run_fwd_bwd(mod, {"x": rnd(rs, *shape)}, 900 + i)
+        r["meta"] = np.array(list(shape) + [800 + i])
+        npz(f"layer_{name}.npz", **r)
+
+
 def dump_unet_activations():
     """The block activations other than SiLU that get_activation offers (modeling/activation.py:4-12): ReLU with
     scale/shift mixing, GELU with additive mixing and attention stages."""
@@ -471,6 +500,8 @@ if __name__ == "__main__":
         dump_layers()
     if "unets" in which:
         dump_unets()
+    if "stages" in which:
+        dump_stage_blocks()
     if "activations" in which:
         dump_unet_activations()
     if "diffusion" in which:

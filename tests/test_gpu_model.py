@@ -94,6 +94,34 @@ def test_resample_blocks_vs_reference(name, kind, use_conv):
         _check_param_grads(m, g, 1.2e-2)
 
 
+@pytest.mark.parametrize("name", ["enc_down", "enc_attn_down", "dec_up", "dec_attn_up", "mid_noattn"])
+def test_encoder_decoder_stages_vs_reference(name):
+    """The stage classes that no shipped configuration uses: embedding-free Encoder / Decoder stages (with and without
+    attention, modeling/blocks.py:422-632) and a MidBlock without attention (:368-419), built through the factories."""
+    from modeling.blocks import MidBlock, get_down_block, get_up_block
+    g = golden(f"layer_stage_{name}.npz")
+    common = dict(norm_groups=32, activation="silu", dropout=0.0)
+    m = {
+        "enc_down": lambda: get_down_block("EncoderDownBlock", in_channels=64, out_channels=128, n_blocks=2, downsample=True,
+                                           downsample_use_conv=True, **common),
+        "enc_attn_down": lambda: get_down_block("EncoderAttnDownBlock", in_channels=64, out_channels=64, n_blocks=1,
+                                                n_dim_head=8, downsample=False, **common),
+        "dec_up": lambda: get_up_block("DecoderUpBlock", in_channels=128, out_channels=64, next_out_channels=None, n_blocks=2,
+                                       upsample=True, upsample_use_conv=True, **common),
+        "dec_attn_up": lambda: get_up_block("DecoderAttnUpBlock", in_channels=64, out_channels=64, next_out_channels=None,
+                                            n_blocks=1, n_dim_head=16, upsample=False, **common),
+        "mid_noattn": lambda: MidBlock(64, n_blocks=1, embedding_dim=None, add_attention=False, **common),
+    }[name]()
+    m = _load(m, int(g["meta"][-1]))
+    x = T(g["in_x"]).to(dev()).requires_grad_(True)
+    out = m(x)
+    assert tuple(out.shape) == tuple(g["out"].shape)
+    assert rel_err(out.float(), T(g["out"])) < BLOCK_FWD
+    out.backward(T(g["gy"]).to(dev()))
+    assert rel_err(x.grad.float(), T(g["gin_x"])) < BLOCK_BWD
+    _check_param_grads(m, g, BLOCK_BWD)
+
+
 @pytest.mark.parametrize("name", ["attn_8x8", "attn_7x7", "attn_16x16_d16"])
 def test_attention_layer_vs_reference(name):
     from modeling.attention import Attention2D
