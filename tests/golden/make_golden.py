@@ -281,6 +281,24 @@ def dump_stage_blocks():
         npz(f"layer_{name}.npz", **r)
 
 
+VARIANT_CFG = dict(
+    in_channels=1, out_channels=2,
+    down_block_types=["UNetDownBlock", "UNetAttnDownBlock", "UNetDownBlock"],
+    up_block_types=["UNetUpBlock", "UNetAttnUpBlock", "UNetUpBlock"],
+    block_out_channels=[64, 64, 128], n_blocks_per_layer=2, n_attention_heads=4, mid_attention=False,
+    norm_groups=16, activation="silu", time_encoding_dim=32, embedding_dim=96, embedding_mixing="addition",
+    n_class_embeddings=None, dropout=0.0, downsample_use_conv=False, upsample_use_conv=False,
+)
+
+
+def dump_unet_variant():
+    """The constructor switches no other fixture exercises, in one network: other channel counts at both ends, three
+    levels with equal widths (identity residuals), two blocks per level, attention by head COUNT, no mid attention, 16
+    groups, additive mixing, no class table (labels and mask are ignored), pooling / plain nearest resampling, and a
+    20x20 image (10x10, 5x5 below)."""
+    unet_case("tiny_variant", VARIANT_CFG, 750, 2, 20, store_all_grads=False)
+
+
 def dump_unet_activations():
     """The block activations other than SiLU that get_activation offers (modeling/activation.py:4-12): ReLU with
     scale/shift mixing, GELU with additive mixing and attention stages."""
@@ -500,6 +518,8 @@ if __name__ == "__main__":
         dump_layers()
     if "unets" in which:
         dump_unets()
+    if "variant" in which:
+        dump_unet_variant()
     if "stages" in which:
         dump_stage_blocks()
     if "activations" in which:

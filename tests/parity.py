@@ -26,6 +26,15 @@ TINY_CFG = dict(
 )
 TINY_ATTN_CFG = dict(TINY_CFG, down_block_types=["UNetDownBlock", "UNetAttnDownBlock"],
                      up_block_types=["UNetAttnUpBlock", "UNetUpBlock"], embedding_mixing="addition")
+# constructor switches no other fixture exercises (tests/golden/make_golden.py: VARIANT_CFG)
+VARIANT_CFG = dict(
+    in_channels=1, out_channels=2,
+    down_block_types=["UNetDownBlock", "UNetAttnDownBlock", "UNetDownBlock"],
+    up_block_types=["UNetUpBlock", "UNetAttnUpBlock", "UNetUpBlock"],
+    block_out_channels=[64, 64, 128], n_blocks_per_layer=2, n_attention_heads=4, mid_attention=False,
+    norm_groups=16, activation="silu", time_encoding_dim=32, embedding_dim=96, embedding_mixing="addition",
+    n_class_embeddings=None, dropout=0.0, downsample_use_conv=False, upsample_use_conv=False,
+)
 
 
 # the networks of tests/golden/samples.npz (trained by the reference, weights stored rounded to bf16)

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.parity import (MINI_CFG, TINY_ATTN_CFG, TINY_CFG, T, det_sd_for, golden, load_cfg, max_abs, rel_err,
+from tests.parity import (MINI_CFG, TINY_ATTN_CFG, TINY_CFG, VARIANT_CFG, T, det_sd_for, golden, load_cfg, max_abs, rel_err,
                           trained_mini_state)
 
 pytestmark = pytest.mark.gpu
@@ -206,6 +206,9 @@ def _unet(name, cfg):
                                       ("rf_mnist", None), ("cos_cifar", None),
                                       # block activations other than SiLU (modeling/activation.py:4-12): not fused into
                                       # the GroupNorm kernels, applied as separate elementwise passes
+                                      # other channel counts at both ends, equal widths, attention by head count, no
+                                      # mid attention, no class table, pooling / plain nearest resampling, 20x20 image
+                                      ("tiny_variant", VARIANT_CFG),
                                       ("tiny_relu", dict(TINY_CFG, activation="relu")),
                                       ("tiny_gelu", dict(TINY_ATTN_CFG, activation="gelu"))])
 def test_unet_vs_reference(name, cfg):
