@@ -71,12 +71,49 @@ __global__ __launch_bounds__(NT) void adamw_ema_kernel(float* __restrict__ p, fl
 
 // advances the step counter and derives the step-dependent scalars on the device, so a captured HIP graph of a
 // whole training step can be replayed: hyper = {lr, 1 - b1^step, 1 - b2^step, ema_decay}
+// Multiplier of the base learning rate at optimizer step k (0-based), the rules of the reference's lr_scheduler
+// (train.py:281-291: transformers.get_scheduler -> torch LambdaLR; formulas of transformers/optimization.py).
+// p0, p1: num_cycles (cosine kinds), power and lr_end / lr_init (polynomial), timescale (inverse_sqrt).
+__host__ __device__ inline double lr_multiplier(int kind, long long k, long long warmup, long long total, double p0,
+                                                double p1) {
+  const double PI = 3.14159265358979323846;
+  if (kind == DM_LR_CONSTANT) return 1.0;
+  if (k < warmup) return (double)k / (double)(warmup > 1 ? warmup : 1);
+  const long long span = total - warmup > 1 ? total - warmup : 1;
+  switch (kind) {
+    case DM_LR_LINEAR: {
+      const double f = (double)(total - k) / (double)span;
+      return f > 0.0 ? f : 0.0;
+    }
+    case DM_LR_COSINE: {
+      const double f = 0.5 * (1.0 + cos(PI * p0 * 2.0 * ((double)(k - warmup) / (double)span)));
+      return f > 0.0 ? f : 0.0;
+    }
+    case DM_LR_COSINE_RESTARTS: {
+      const double progress = (double)(k - warmup) / (double)span;
+      if (progress >= 1.0) return 0.0;
+      const double f = 0.5 * (1.0 + cos(PI * fmod(p0 * progress, 1.0)));
+      return f > 0.0 ? f : 0.0;
+    }
+    case DM_LR_POLYNOMIAL: {   // p1 = lr_end / lr_init
+      if (k > total) return p1;
+      const double remaining = 1.0 - (double)(k - warmup) / (double)(total - warmup);
+      return (1.0 - p1) * pow(remaining, p0) + p1;
+    }
+    case DM_LR_INVERSE_SQRT:   // p0 = timescale
+      return 1.0 / sqrt(((double)k + (p0 - (double)warmup)) / p0);
+    default:                   // DM_LR_CONSTANT_WITH_WARMUP
+      return 1.0;
+  }
+}
+
 __global__ void optimizer_tick_kernel(long long* step, float* hyper, float lr, float b1, float b2, float ema_inv_gamma,
-                                      float ema_power, float ema_max_decay) {
+                                      float ema_power, float ema_max_decay, int lr_kind, long long lr_warmup,
+                                      long long lr_total, double lr_p0, double lr_p1) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const long long s = step[0] + 1;
   step[0] = s;
-  hyper[0] = lr;
+  hyper[0] = (float)((double)lr * lr_multiplier(lr_kind, s - 1, lr_warmup, lr_total, lr_p0, lr_p1));
   hyper[1] = (float)(1.0 - pow((double)b1, (double)s));
   hyper[2] = (float)(1.0 - pow((double)b2, (double)s));
   // warm-up EMA: decay = min(1 - (1 + (s-1)/inv_gamma)^-power, max), 0 on the first step
@@ -93,11 +130,27 @@ __global__ void optimizer_tick_kernel(long long* step, float* hyper, float lr, f
 
 extern "C" int dm_optimizer_tick(long long* step, float* hyper, float lr, float b1, float b2, float ema_inv_gamma,
                                  float ema_power, float ema_max_decay, void* stream) {
-  DM_REQUIRE(step && hyper, DM_ERR_ARG, "dm_optimizer_tick: null argument");
-  hipLaunchKernelGGL(optimizer_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, hyper, lr, b1, b2, ema_inv_gamma,
-                     ema_power, ema_max_decay);
+  return dm_optimizer_tick_lr(step, hyper, lr, DM_LR_CONSTANT, 0, 0, 0.0, 0.0, b1, b2, ema_inv_gamma, ema_power,
+                              ema_max_decay, stream);
+}
+
+extern "C" int dm_optimizer_tick_lr(long long* step, float* hyper, float base_lr, int kind, long long warmup,
+                                    long long total, double p0, double p1, float b1, float b2, float ema_inv_gamma,
+                                    float ema_power, float ema_max_decay, void* stream) {
+  DM_REQUIRE(step && hyper, DM_ERR_ARG, "dm_optimizer_tick_lr: null argument");
+  DM_REQUIRE(kind >= DM_LR_CONSTANT && kind <= DM_LR_INVERSE_SQRT, DM_ERR_ARG, "dm_optimizer_tick_lr: unknown schedule %d", kind);
+  DM_REQUIRE(warmup >= 0 && total >= 0, DM_ERR_ARG, "dm_optimizer_tick_lr: negative step counts");
+  DM_REQUIRE(kind != DM_LR_POLYNOMIAL || total > warmup, DM_ERR_ARG,
+             "dm_optimizer_tick_lr: the polynomial schedule needs total > warmup steps");
+  DM_REQUIRE(kind != DM_LR_INVERSE_SQRT || p0 > 0.0, DM_ERR_ARG, "dm_optimizer_tick_lr: the inverse-sqrt timescale must be positive");
+  hipLaunchKernelGGL(optimizer_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, hyper, base_lr, b1, b2,
+                     ema_inv_gamma, ema_power, ema_max_decay, kind, warmup, total, p0, p1);
   DM_CHECK_LAUNCH();
   return DM_OK;
+}
+
+extern "C" double dm_lr_multiplier(int kind, long long k, long long warmup, long long total, double p0, double p1) {
+  return lr_multiplier(kind, k, warmup, total, p0, p1);
 }
 
 extern "C" int dm_sumsq_partials(void) { return NPART; }

@@ -118,6 +118,9 @@ _SIGNATURES = {
     "dm_grad_norm": (c_int, [P, c_long, c_float, P, P, P]),
     "dm_adamw_ema_step": (c_int, [P, P, P, P, P, P, P, c_float, c_long] + [c_float] * 8 + [P, c_float, c_int, P]),
     "dm_optimizer_tick": (c_int, [P, P] + [c_float] * 6 + [P]),
+    "dm_optimizer_tick_lr": (c_int, [P, P, c_float, c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_double,
+                                     ctypes.c_double] + [c_float] * 5 + [P]),
+    "dm_lr_multiplier": (ctypes.c_double, [c_int] + [ctypes.c_longlong] * 3 + [ctypes.c_double] * 2),
 }
 
 EXPORTS = tuple(_SIGNATURES) + ("dm_last_error",)

@@ -96,12 +96,66 @@ class FlatArena:
         return flat.view(shape)
 
 
+LR_KINDS = {"constant": 0, "constant_with_warmup": 1, "linear": 2, "cosine": 3, "cosine_with_restarts": 4,
+            "polynomial": 5, "inverse_sqrt": 6}
+
+
+def lr_schedule_args(name, lr, warmup_steps=0, max_steps=None, cfg=None):
+    """(kind, warmup, total, p0, p1) of dm_optimizer_tick_lr for the schedule that
+    transformers.get_scheduler(name, optimizer, num_warmup_steps, num_training_steps, **cfg) builds in the reference
+    (train.py:281-291), with its defaults and its argument errors."""
+    if name is None:
+        return (0, 0, 0, 0.0, 0.0)
+    if name not in LR_KINDS:
+        raise ValueError(f'unknown lr scheduler "{name}" (known: {sorted(LR_KINDS)})')
+    # cfg is what the reference splats into get_scheduler (TrainArgs.lr_schduler_cfg): its one legal key is
+    # scheduler_specific_kwargs, the dict that reaches the schedule function
+    top = dict(cfg or {})
+    cfg = dict(top.pop("scheduler_specific_kwargs", None) or {})
+    if top:
+        raise TypeError(f"get_scheduler() got an unexpected keyword argument {sorted(top)[0]!r}")
+    kind = LR_KINDS[name]
+    if kind <= 1:
+        cfg = {}   # (get_scheduler does not pass them on to the constant rules)
+    if kind >= 2 and kind <= 5 and max_steps is None:
+        raise ValueError(f"{name} requires `num_training_steps`, please provide that argument.")
+    p0 = p1 = 0.0
+    if kind == 3:
+        p0 = float(cfg.pop("num_cycles", 0.5))
+    elif kind == 4:
+        p0 = float(int(cfg.pop("num_cycles", 1)))
+    elif kind == 5:
+        lr_end, p0 = float(cfg.pop("lr_end", 1e-7)), float(cfg.pop("power", 1.0))
+        if not lr > lr_end:
+            raise ValueError(f"lr_end ({lr_end}) must be smaller than initial lr ({lr})")
+        p1 = lr_end / lr
+    elif kind == 6:
+        timescale = cfg.pop("timescale", None)
+        p0 = float(timescale if timescale is not None else (warmup_steps or 10_000))
+    if cfg:
+        raise TypeError(f"unexpected arguments for the {name} lr scheduler: {sorted(cfg)}")
+    return (kind, 0 if kind == 0 else int(warmup_steps), int(max_steps or 0), p0, p1)
+
+
 class TrainStep:
-    def __init__(self, model, scheduler, lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2,
+    def __init__(self, model, scheduler, lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=None,
                  clip_grad_norm: Optional[float] = 1.0, use_ema=True, ema_inv_gamma=1.0, ema_power=0.75,
-                 ema_max_decay=0.9999, p_uncond=0.2, bucket_mb=25, process_group=None, side_wgrad=None, wgrad_group=None):
+                 ema_max_decay=0.9999, p_uncond=0.2, bucket_mb=25, process_group=None, side_wgrad=None, wgrad_group=None,
+                 optimizer="adamw", lr_scheduler=None, lr_warmup_steps=0, max_steps=None, lr_scheduler_cfg=None):
         self.model, self.scheduler = model, scheduler
+        # train.py:265-279: torch.optim.AdamW (decoupled decay, default 1e-2) or torch.optim.Adam (default: none; with
+        # none the two are the same update)
+        if optimizer not in ("adamw", "adam"):
+            raise ValueError(f"unknown optimizer {optimizer}")
+        if weight_decay is None:
+            weight_decay = 1e-2 if optimizer == "adamw" else 0.0
+        elif optimizer == "adam" and weight_decay:
+            raise NotImplementedError("Adam with a coupled L2 penalty is not built; the reference never sets one")
+        self.optimizer_name = optimizer
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        # lr is the BASE rate; the rate of a step comes from the schedule, evaluated on the device (train.py:446-447)
+        self.lr_scheduler_name = lr_scheduler
+        self.lr_sched = lr_schedule_args(lr_scheduler, lr, lr_warmup_steps, max_steps, lr_scheduler_cfg)
         self.clip = float(clip_grad_norm) if clip_grad_norm else 0.0
         self.p_uncond = p_uncond
         self.side_wgrad = side_wgrad
@@ -404,8 +458,8 @@ class TrainStep:
         if self.clip > 0:
             check(lib.dm_grad_norm(a.grad.data_ptr(), a.numel, gscale, self.partials.data_ptr(), self.norm.data_ptr(), st))
         ig, pw, mx = self.ema_cfg
-        check(lib.dm_optimizer_tick(self.step_dev.data_ptr(), self.hyper.data_ptr(), self.lr, self.betas[0],
-                                    self.betas[1], ig, pw, mx, st))
+        check(lib.dm_optimizer_tick_lr(self.step_dev.data_ptr(), self.hyper.data_ptr(), self.lr, *self.lr_sched,
+                                       self.betas[0], self.betas[1], ig, pw, mx, st))
         check(lib.dm_adamw_ema_step(a.data.data_ptr(), a.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                     self.ema.data_ptr() if self.ema is not None else None, self.w16.data_ptr(),
                                     self.norm.data_ptr() if self.clip > 0 else None, self.clip, a.numel, self.lr,
@@ -414,6 +468,10 @@ class TrainStep:
         self._transpose_mirror()
         self.steps += 1
         ops.WEIGHTS_EPOCH += 1  # packed bf16 copies of the weights are stale now
+
+    def last_lr(self):
+        """lr_scheduler.get_last_lr()[0] of the reference's log line (train.py:639-640): the rate the NEXT step runs at."""
+        return self.lr * lib.dm_lr_multiplier(self.lr_sched[0], self.steps, *self.lr_sched[1:])
 
     def _backward_and_update(self, loss):
         self._backward(loss)
@@ -491,6 +549,13 @@ class TrainStep:
                  "params": list(range(n))}
         sd = {"global_steps": self.steps, "model_state_dict": self.model_state_dict(),
               "optimizer_state_dict": {"state": opt_state, "param_groups": [group]}}
+        if self.lr_scheduler_name is not None:
+            # as torch's LambdaLR leaves them (train.py:390-391): the group holds the current rate and the base rate
+            # as `initial_lr`; the scheduler's own state is its position
+            group["lr"], group["initial_lr"] = self.last_lr(), self.lr
+            sd["lr_scheduler_state_dict"] = {"base_lrs": [self.lr], "last_epoch": self.steps, "_step_count": self.steps + 1,
+                                             "_get_lr_called_within_step": False, "_last_lr": [self.last_lr()],
+                                             "lr_lambdas": [None]}
         if self.ema is not None:
             ig, pw, mx = self.ema_cfg
             sd["ema_model_state_dict"] = {
@@ -517,7 +582,8 @@ class TrainStep:
             a.view_of(self.v, i).copy_(st["exp_avg_sq"])
             steps = max(steps, int(float(st["step"])))
         g = sd["optimizer_state_dict"]["param_groups"][0]
-        loaded = (g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"])
+        base_lr = g.get("initial_lr", g["lr"]) if self.lr_scheduler_name is not None else g["lr"]
+        loaded = (base_lr, tuple(g["betas"]), g["eps"], g["weight_decay"])
         if self._update_captured and loaded != (self.lr, tuple(self.betas), self.eps, self.wd):
             # those scalars are kernel arguments: a graph captured before this call would go on using the old ones
             raise RuntimeError("load_state_dict: the checkpoint's optimizer hyper-parameters differ from the ones a captured "

@@ -392,6 +392,25 @@ int dm_adamw_ema_step(float* p, float* g, float* m, float* v, float* ema, void* 
  * When `hyper` (device, 4 floats) is passed to dm_adamw_ema_step it overrides lr, bc1, bc2 and ema_decay. */
 int dm_optimizer_tick(long long* step, float* hyper, float lr, float b1, float b2, float ema_inv_gamma, float ema_power,
                       float ema_max_decay, void* stream);
+/* The same with a learning-rate schedule evaluated on the device, so that a replayed HIP graph follows it:
+ * hyper[0] = base_lr * multiplier(step - 1). Replaces lr_scheduler.step() of train.py:446-447 / :281-291
+ * (transformers.get_scheduler -> torch LambdaLR; optimizer step k, 0-based, runs at base_lr * lambda(k)).
+ * kind: the DM_LR_* rules below, formulas of transformers/optimization.py. warmup / total = num_warmup_steps /
+ * num_training_steps. p0: num_cycles (cosine 0.5, cosine_with_restarts 1), power (polynomial), timescale
+ * (inverse_sqrt); p1: lr_end / lr_init (polynomial). dm_lr_multiplier evaluates the same rule on the host. */
+enum {
+  DM_LR_CONSTANT = 0,
+  DM_LR_CONSTANT_WITH_WARMUP = 1,
+  DM_LR_LINEAR = 2,
+  DM_LR_COSINE = 3,
+  DM_LR_COSINE_RESTARTS = 4,
+  DM_LR_POLYNOMIAL = 5,
+  DM_LR_INVERSE_SQRT = 6
+};
+int dm_optimizer_tick_lr(long long* step, float* hyper, float base_lr, int kind, long long warmup, long long total,
+                         double p0, double p1, float b1, float b2, float ema_inv_gamma, float ema_power,
+                         float ema_max_decay, void* stream);
+double dm_lr_multiplier(int kind, long long k, long long warmup, long long total, double p0, double p1);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Either side of the path: the data set resident in HBM, and the memorisation metric of the evaluation.

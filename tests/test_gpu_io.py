@@ -167,6 +167,71 @@ def test_run_directory_roundtrip_and_resume(tmp_path):
         _step(use_ema=False).ema_state_dict()
 
 
+def test_lr_schedule_on_device_resume_and_graph_replay(tmp_path):
+    """lr_scheduler / optimizer options of the reference's trainer (train.py:265-291, 446-447): the rate of every step
+    comes from the schedule evaluated on the device, so a replayed HIP graph follows it; a resumed run continues bit
+    for bit; the saved scheduler and optimizer state load into torch's LambdaLR / AdamW at the same position."""
+    transformers = pytest.importorskip("transformers")
+    from dm_hip import lib, ops
+    from harness import checkpoint as C
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(4, 3, 16, 16, generator=g) * 2 - 1).to(dev())
+    cls = torch.randint(0, 10, (4,), generator=g).to(dev())
+    kw = dict(use_ema=True, lr_scheduler="cosine", lr_warmup_steps=2, max_steps=8)
+    a = _step(**kw)
+    want = [2e-4 * lib.dm_lr_multiplier(a.lr_sched[0], k, *a.lr_sched[1:]) for k in range(9)]
+
+    def on_device(step_obj, k):   # the fp32 rate the device derived for optimizer step k (its cos may differ in the last bit)
+        return abs(float(step_obj.hyper[0]) - want[k]) <= 2e-7 * want[k]
+    assert want[0] == 0.0 and want[2] == 2e-4 and 0 < want[7] < want[3] < 2e-4 and abs(want[8]) < 1e-20
+    torch.manual_seed(5); torch.cuda.manual_seed(5)
+    p0 = a.arena.data.clone()
+    a.step(x, cls)
+    assert float(a.hyper[0]) == 0.0 and torch.equal(a.arena.data, p0)      # a warm-up from zero: step 0 moves nothing
+    for k in (1, 2):
+        a.step(x, cls)
+        assert on_device(a, k) and a.last_lr() == want[k + 1]
+    assert not torch.equal(a.arena.data, p0)
+    out = str(tmp_path / "run")
+    C.save_latest_ckpt(a, out)
+    torch.manual_seed(6); torch.cuda.manual_seed(6)
+    la = [float(a.step(x, cls)) for _ in range(2)]
+    b = _step(seed=99, **kw)
+    C.load_latest_ckpt(b, out)
+    assert b.steps == 3 and b.lr == 2e-4
+    torch.manual_seed(6); torch.cuda.manual_seed(6)
+    lb = [float(b.step(x, cls)) for _ in range(2)]
+    assert la == lb and torch.equal(a.arena.data, b.arena.data) and on_device(b, 4)
+    # torch's objects take the saved state as their own and stand at the same position
+    sd = torch.load(os.path.join(out, "latest.pt"), weights_only=True)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in a.arena.shapes]
+    opt = torch.optim.AdamW(params, lr=2e-4, betas=(0.9, 0.99))
+    sch = transformers.get_scheduler("cosine", optimizer=opt, num_warmup_steps=2, num_training_steps=8)
+    opt.load_state_dict(sd["optimizer_state_dict"])
+    sch.load_state_dict(sd["lr_scheduler_state_dict"])
+    assert sch.last_epoch == 3 and abs(sch.get_last_lr()[0] - want[3]) < 1e-18 and opt.param_groups[0]["lr"] == want[3]
+    opt.step(); sch.step()
+    assert abs(opt.param_groups[0]["lr"] - want[4]) < 1e-18
+    # one captured update follows the schedule on replay
+    graph = ops.new_graph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            b.update()
+        for k in (6, 7):     # (capture runs nothing: the step counter is still 5)
+            graph.replay()
+            side.synchronize()
+            assert on_device(b, k - 1) and int(b.step_dev) == k
+    torch.cuda.current_stream().wait_stream(side)
+    # plain Adam (train.py:266-267): no decay; an unknown optimizer or a coupled penalty is refused
+    assert _step(optimizer="adam").wd == 0.0 and _step().wd == 1e-2
+    with pytest.raises(ValueError):
+        _step(optimizer="sgd")
+    with pytest.raises(NotImplementedError):
+        _step(optimizer="adam", weight_decay=0.1)
+
+
 def test_data_order_and_flips_resume_mid_epoch(tmp_path):
     """A run resumed from latest.pt sees the batches the uninterrupted run would have seen next: same rows (the
     shuffle order taken up at epochs / steps_in_epoch, train.py:598-605) and the same flips (the flip generator's state

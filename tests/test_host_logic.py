@@ -209,3 +209,40 @@ def test_latest_ckpt_written_in_the_reference_form_is_read_without_unpickling_co
     torch.save({"x": Evil()}, path)
     with pytest.raises(Exception):
         _read_latest(path)
+
+
+def test_lr_schedules_match_transformers_get_scheduler():
+    """The learning-rate rules evaluated by dm_optimizer_tick_lr (host twin dm_lr_multiplier) against the schedulers
+    the reference builds (train.py:281-291: transformers.get_scheduler -> LambdaLR), for every optimizer step up to
+    and beyond num_training_steps; argument defaults and errors as transformers has them."""
+    transformers = pytest.importorskip("transformers")
+    from dm_hip import lib
+    from harness.train_step import lr_schedule_args
+    base = 2e-4
+    cases = [("constant", 0, None, {}), ("constant_with_warmup", 7, None, {}), ("linear", 5, 40, {}), ("linear", 0, 40, {}),
+             ("cosine", 5, 40, {}), ("cosine", 3, 40, {"num_cycles": 1.5}), ("cosine_with_restarts", 4, 40, {"num_cycles": 3}),
+             ("polynomial", 5, 40, {}), ("polynomial", 5, 40, {"power": 2.0, "lr_end": 1e-5}), ("inverse_sqrt", 6, None, {}),
+             ("inverse_sqrt", 0, None, {"timescale": 20})]
+    for name, warmup, total, cfg in cases:
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=base)
+        cfg = {"scheduler_specific_kwargs": cfg} if cfg else {}      # TrainArgs.lr_schduler_cfg, splatted as train.py:284-290 does
+        ref = transformers.get_scheduler(name, optimizer=opt, num_warmup_steps=warmup, num_training_steps=total, **cfg)
+        args = lr_schedule_args(name, base, warmup, total, cfg)
+        for k in range(50):
+            want = opt.param_groups[0]["lr"]                    # the rate optimizer step k runs at
+            got = base * lib.dm_lr_multiplier(args[0], k, *args[1:])
+            assert abs(got - want) <= 1e-12 * base + 1e-15 * abs(want), (name, cfg, k, got, want)
+            opt.step()
+            ref.step()
+    assert lr_schedule_args(None, base) == (0, 0, 0, 0.0, 0.0)
+    with pytest.raises(ValueError):
+        lr_schedule_args("linear", base, 5, None)
+    with pytest.raises(ValueError):
+        lr_schedule_args("no_such_rule", base, 5, 10)
+    with pytest.raises(ValueError):
+        lr_schedule_args("polynomial", base, 5, 10, {"scheduler_specific_kwargs": {"lr_end": 1.0}})
+    with pytest.raises(TypeError):
+        lr_schedule_args("cosine", base, 5, 10, {"num_cycles": 2})
+    with pytest.raises(TypeError):
+        lr_schedule_args("cosine", base, 5, 10, {"scheduler_specific_kwargs": {"cycles": 2}})
