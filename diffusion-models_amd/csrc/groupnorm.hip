@@ -21,6 +21,7 @@
 
 extern int g_dm_gn_fused;
 extern int g_dm_gn_bwd16;
+extern int g_dm_gn_min_ppt;
 
 // Scratch of the entry point that allocates nothing (dm_groupnorm_act_fwd_noalloc): a fixed device array that
 // stands in for the caller-provided workspace. Every GPU the library runs on holds its own copy at its own
@@ -612,6 +613,18 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { xr[i][k] = xv[k]; dr[i][k] = dv[k]; }
   }
+  constexpr bool EARLY = EXTRA && PPT <= 2;
+  const bool two = EXTRA && a.dextra2 != nullptr;
+  u32x4_t ew[PPT], ew2[PPT];
+  auto fetch = [&](int i, int p) {
+    const size_t o = (base + (EXACT ? p : min(p, a.HW - 1))) * a.C + (cok ? c : 0);
+    ew[i] = *(const u32x4_t*)(a.dextra + o);
+    if (two) ew2[i] = *(const u32x4_t*)(a.dextra2 + o);
+  };
+  if (EARLY) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) fetch(i, pl + i * PLN);
+  }
   // threads 0..63 own one channel of the slab each: its constants are fetched here, beside the slab, and kept (in
   // LDS: the 16-pixel variant has no register to spare) for the parameter-side results behind the reduction, which
   // then need no second trip to memory
@@ -727,15 +740,10 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
   const int dxs = c < a.C1 ? a.C1 : a.C2;
   // The addends are read AHEAD pixels in front of their use (a window of registers, the slab has taken the rest): a
   // load per pixel issued where it is needed would put its full latency into every iteration.
+  // (Slabs of up to 2 pixels per thread have the registers to hold all their addends: those were fetched at the
+  // top of the kernel, beside the slab, which takes the second trip to memory out of a small layer's latency chain.)
   constexpr int AHEAD = PPT > 2 ? 2 : 1;
-  const bool two = EXTRA && a.dextra2 != nullptr;
-  u32x4_t ew[PPT], ew2[PPT];
-  auto fetch = [&](int i, int p) {
-    const size_t o = (base + (EXACT ? p : min(p, a.HW - 1))) * a.C + c;
-    ew[i] = *(const u32x4_t*)(a.dextra + o);
-    if (two) ew2[i] = *(const u32x4_t*)(a.dextra2 + o);
-  };
-  if (EXTRA) {
+  if (EXTRA && !EARLY) {
 #pragma unroll
     for (int i = 0; i < AHEAD && i < PPT; ++i) fetch(i, pl + i * PLN);
   }
@@ -745,7 +753,7 @@ __global__ __launch_bounds__(MAXT) void gn_bwd_fused_kernel(GnArgs a) {
     unsigned xw[4] = {xr[i][0], xr[i][1], xr[i][2], xr[i][3]}, dw[4] = {dr[i][0], dr[i][1], dr[i][2], dr[i][3]};
     // opaque: unpacking and address arithmetic stay with their pixel instead of being hoisted for the whole slab
     asm volatile("" : "+v"(xw[0]), "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]), "+v"(dw[0]), "+v"(dw[1]), "+v"(dw[2]), "+v"(dw[3]), "+v"(p));
-    if (EXTRA && i + AHEAD < PPT) fetch(i + AHEAD, p + AHEAD * PLN);   // (address from the opaque p: stays here)
+    if (EXTRA && !EARLY && i + AHEAD < PPT) fetch(i + AHEAD, p + AHEAD * PLN);   // (address from the opaque p: stays here)
     u32x4_t ow;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -776,7 +784,14 @@ int slab_width(int cg) {
 // pixels per thread: the smallest of 1, 2, 4, 8 with at most 64 pixel lanes (128 beyond 512 pixels)
 int fused_ppt(const GnArgs& a, bool bwd) {
   for (int ppt = 1; ppt < 8; ppt *= 2)
-    if (dm_cdiv(a.HW, ppt) <= 64) return ppt;
+    if (dm_cdiv(a.HW, ppt) <= 64) {
+      // Small slabs: a CU holds at most 32 waves, so with one pixel per thread it has 32 KB per tensor in flight, and
+      // a workgroup lives for one memory round trip plus its reductions (~5 us) whatever its size: the kernel runs at
+      // (bytes in flight) / (that latency) - 3 TB/s at 64 pixels. More pixels per thread in smaller workgroups put more
+      // bytes in flight per wave (g_dm_gn_min_ppt; never fewer than 8 pixel lanes, one wave).
+      while (ppt < g_dm_gn_min_ppt && ppt < 8 && dm_cdiv(a.HW, 2 * ppt) >= 8) ppt *= 2;
+      return ppt;
+    }
   return (bwd && g_dm_gn_bwd16 && a.HW > 512) ? 16 : 8;
 }
 int fused_threads(const GnArgs& a, bool bwd) {   // one thread per (pixel lane, 8-channel vector)

@@ -61,6 +61,8 @@ int dm_abi_version(void);
  *                         multiples of 128) take the streaming kernel; 2: wherever the channel counts allow; 0: never
  *   "patch_direct" (1)    plain outputs of the patch kernel leave the accumulator registers directly (0: through LDS,
  *                         as the outputs with a GroupNorm epilogue always do); bit-identical either way
+ *   "gn_min_ppt" (4)      single-pass GroupNorm kernels: least pixels per thread (1, 2, 4, 8) on images small enough to
+ *                         leave 8 pixel lanes - smaller workgroups with more bytes in flight per wave (8x8 images)
  *   "dgrad_subpixel" (1)  stride-2 data gradients run by output-pixel parity class
  *   "wgrad_row3" (1)      3x3 weight gradients share one staged input row among the 3 taps of a kernel row
  *   "wgrad_row9" (3)      ... or all nine taps per workgroup: 0 never, 1 from 512 input channels, 3 also from 256 input
