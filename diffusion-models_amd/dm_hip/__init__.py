@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdm_hip.so")
+# (DM_HIP_LIBRARY: another build of the same library, e.g. to compare two builds on one machine)
+LIB_PATH = os.environ.get("DM_HIP_LIBRARY") or os.path.join(_HERE, "libdm_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

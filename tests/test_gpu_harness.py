@@ -24,6 +24,16 @@ def _worst_params(a, b, lr):
     return sorted(rows, reverse=True)[:8]
 
 
+def _grad_diffs(a, b):
+    """Names of the parameters whose gradients differ between two TrainSteps, with the largest difference."""
+    rows = []
+    for (n, p), o in zip(a.arena.params, a.arena.offsets):
+        ga, gb = a.arena.grad[o:o + p.numel()], b.arena.grad[o:o + p.numel()]
+        if not torch.equal(ga, gb):
+            rows.append((n, float((ga - gb).abs().max()), float(ga.abs().max())))
+    return rows[:10], len(rows)
+
+
 def _make_step(seed=11, **kw):
     from diffusion.scheduler import get_scheduler
     from harness.train_step import TrainStep
@@ -178,7 +188,8 @@ def test_graph_replay_single_and_segmented_equals_eager():
         graphs[b][0]()
         graphs[c][0]()
         torch.cuda.synchronize()
-        assert torch.equal(a.arena.grad, b.arena.grad) and torch.equal(a.arena.grad, c.arena.grad)
+        assert torch.equal(a.arena.grad, b.arena.grad), _grad_diffs(a, b)
+        assert torch.equal(a.arena.grad, c.arena.grad), _grad_diffs(a, c)
         a.update()
         graphs[b][1].replay()
         graphs[c][1].replay()
@@ -210,3 +221,106 @@ def test_captured_graph_survives_larger_eager_calls():
         torch.cuda.synchronize()
         again = gp(z, t).clone()
     assert torch.equal(first, again)
+
+
+@pytest.mark.parametrize("mode", ["single_graph", "segmented"])
+def test_graph_only_training_loop_without_host_sync_equals_eager(mode):
+    """A training loop that is nothing but graph launches - backward graph (or the chain of graphs cut at the bucket
+    boundaries), update graph, backward graph, ... - with NO host synchronisation between them, as bench.py and a real
+    run replay it, against the same steps run eagerly: every loss and the final parameters agree bit for bit. (The
+    other replay tests synchronise between launches; here two or three graphs are in flight at any time, and the head
+    of one - the embedding path on its own branch - runs beside the tail of the one before.)"""
+    from dm_hip import ops
+    x, cls = _batch()
+    g = torch.Generator().manual_seed(5)
+    B = x.shape[0]
+    mask = (torch.rand(B, generator=g) < 0.25).float().to(dev())
+    eps = torch.randn(B, 3, 16, 16, generator=g).to(dev())
+    t = torch.randint(0, 1000, (B,), generator=g).to(dev())
+    args = (x, cls, mask, eps, t)
+    for rep in range(3):
+        a, c = _make_step(bucket_mb=1), _make_step(bucket_mb=1)
+        c.reducer.force = mode == "segmented"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        ops.FORCE_REPACK = True
+        try:
+            with torch.cuda.stream(side):
+                c._backward(c.loss_given_noise(*args), overlap=False)    # warm-up outside capture
+                c.arena.grad.zero_()
+                torch.cuda.synchronize()
+            if mode == "segmented":
+                loss_c = c.capture_segmented(loss_fn=lambda: c.loss_given_noise(*args), stream=side)
+                backward = c.replay_segmented
+            else:
+                g1 = ops.new_graph()
+                with torch.cuda.graph(g1, stream=side):
+                    lc = c.loss_given_noise(*args)
+                    c._backward(lc, overlap=False)
+                loss_c, backward = lc.detach(), g1.replay
+            g2 = ops.new_graph()
+            with torch.cuda.graph(g2, stream=side):
+                c.update()
+        finally:
+            ops.FORCE_REPACK = False
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        n, ref, got = 12, [], []
+        for _ in range(n):
+            la = a.loss_given_noise(*args)
+            a._backward(la, overlap=False)
+            a.update()
+            ref.append(float(la.detach()))
+        torch.cuda.synchronize()
+        for _ in range(n):
+            backward()
+            got.append(loss_c.clone())
+            g2.replay()
+        torch.cuda.synchronize()
+        got = [float(v) for v in got]
+        assert got == ref, (rep, [i for i in range(n) if got[i] != ref[i]])
+        assert torch.equal(a.arena.data, c.arena.data), _worst_params(a, c, 2e-4)
+
+
+def test_back_to_back_replays_of_one_graph_equal_eager():
+    """The forward + backward graph launched twice in a row without host synchronisation, 300 times over: the loss
+    of every second launch equals the eager loss bit for bit. The second launch finds the queues primed, so its
+    branches (embedding path beside the first convolutions) run at full speed and overlap differently from a launch
+    into an idle GPU; this is the sharpest detector this suite has for results that depend on timing (a build whose
+    embedding kernels dropped one product term in 16 lanes under exactly these conditions failed 3-30 % of the pairs
+    and passed every other test)."""
+    from dm_hip import ops
+    x, cls = _batch()
+    g = torch.Generator().manual_seed(5)
+    B = x.shape[0]
+    mask = (torch.rand(B, generator=g) < 0.25).float().to(dev())
+    eps = torch.randn(B, 3, 16, 16, generator=g).to(dev())
+    t = torch.randint(0, 1000, (B,), generator=g).to(dev())
+    args = (x, cls, mask, eps, t)
+    a, c = _make_step(bucket_mb=1), _make_step(bucket_mb=1)
+    want = float(a.loss_given_noise(*args).detach())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    ops.FORCE_REPACK = True
+    try:
+        with torch.cuda.stream(side):
+            c._backward(c.loss_given_noise(*args), overlap=False)    # warm-up outside capture
+            torch.cuda.synchronize()
+        g1 = ops.new_graph()
+        with torch.cuda.graph(g1, stream=side):
+            lc = c.loss_given_noise(*args)
+            c._backward(lc, overlap=False)
+        lc = lc.detach()
+    finally:
+        ops.FORCE_REPACK = False
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    bad = []
+    for i in range(300):
+        g1.replay()
+        g1.replay()
+        torch.cuda.synchronize()
+        if float(lc) != want:
+            bad.append((i, float(lc)))
+    assert not bad, (want, len(bad), bad[:5])
+
