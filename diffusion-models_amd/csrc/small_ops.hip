@@ -17,6 +17,49 @@ __global__ void timestep_embed_kernel(const int64_t* __restrict__ t, const float
   out[(size_t)b * 2 * half + half + k] = cosf(a);
 }
 
+// Staging of an fp32 tile into LDS for the embedding-path GEMMs. These launches are small (a few dozen workgroups) and
+// sit on the step's critical path at both ends of the network, so what matters is the length of a workgroup's chain of
+// memory round trips (each a few microseconds behind the cold TLBs and caches of a step): a thread fetches its share of
+// the tile as 16-byte pieces, eight of them in flight at a time, instead of one float per loop iteration (32-48
+// dependent trips for a 64 x 128 tile). Tile element (r, c4 * 4 ..) comes from src[r * ld + c4 * 4 ..] when
+// r < rows_valid (else zeros); `put(r, c, v)` files the four values. cols must be a multiple of 4 and src + r * ld
+// 16-byte aligned (the callers check).
+template <typename Put>
+__device__ __forceinline__ void stage_tile4(const float* __restrict__ src, long ld, int rows, int cols, int rows_valid,
+                                            Put put) {
+  const int c4n = cols >> 2, total = rows * c4n;
+  for (int base = threadIdx.x; base < total; base += NT * 8) {
+    f32x4_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = base + j * NT;
+      const int r = i / c4n, c4 = i - r * c4n;
+      v[j] = (i < total && r < rows_valid) ? *(const f32x4_t*)(src + (long)r * ld + c4 * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = base + j * NT;
+      if (i < total) {
+        const int r = i / c4n, c4 = i - r * c4n;
+        put(r, c4 * 4, v[j]);
+      }
+    }
+  }
+}
+__device__ __forceinline__ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// acc += a * b as ONE v_fmac_f32, spelled out. Left to the compiler, the forward kernels' inner loops become packed
+// v_pk_fma_f32 on pairs of rows, and for the odd elements of a 16-byte LDS read in the form `op_sel:[0,1,0]` (the low
+// lane multiplies by the HIGH register of the second source pair). On MI355X that form was measured to drop the low
+// lane's product in lanes 48-63 now and then while a matrix-core kernel of another stream shares the compute unit: one
+// term x[m][k] * w[n][k] missing from 16 neighbouring outputs of an even row, in 80 % of the launches beside a bf16 GEMM
+// and in a few percent of training steps (beside the first convolutions); the same loop with plain FMAs never did
+// (tools/experiments/repro_linear_group.py). The loops are bound by their LDS reads, so the unpacked form costs
+// nothing. It also fixes the contraction: a row's result must not depend on its place in the tile.
+__device__ __forceinline__ void fma_acc(float& acc, float a, float b) {
+  asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 // ---- y[m][n] = sum_k f(x[m][k]) w[n][k] + bias[n]; block = 64 columns x 16 rows
 constexpr int LIN_ROWS = 16, LIN_COLS = 64;
 __global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -24,24 +67,50 @@ __global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict_
                                                         int K, int N, int act_in) {
   extern __shared__ float lds[];
   float* xs = lds;                    // [LIN_ROWS][K]
-  float* ws = lds + LIN_ROWS * K;     // [LIN_COLS][K+1]
+  float* ws = lds + LIN_ROWS * K;     // [LIN_COLS][K+4]: 16-byte reads along k, eight lanes cover the 32 banks
   const int n0 = blockIdx.x * LIN_COLS, m0 = blockIdx.y * LIN_ROWS;
-  for (int i = threadIdx.x; i < LIN_ROWS * K; i += NT) {
-    const int r = i / K, k = i - r * K;
-    float v = (m0 + r < M) ? x[(size_t)(m0 + r) * K + k] : 0.f;
-    xs[i] = act_in ? dm_silu(v) : v;
-  }
-  for (int i = threadIdx.x; i < LIN_COLS * K; i += NT) {
-    const int c = i / K, k = i - c * K;
-    ws[c * (K + 1) + k] = (n0 + c < N) ? w[(size_t)(n0 + c) * K + k] : 0.f;
+  const bool vec = K % 4 == 0 && aligned16(x) && aligned16(w);
+  if (vec) {
+    stage_tile4(x + (size_t)m0 * K, K, LIN_ROWS, K, M - m0, [&](int r, int k, f32x4_t v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xs[r * K + k + e] = act_in ? dm_silu(v[e]) : v[e];
+    });
+    stage_tile4(w + (size_t)n0 * K, K, LIN_COLS, K, N - n0, [&](int c, int k, f32x4_t v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ws[c * (K + 4) + k + e] = v[e];
+    });
+  } else {
+    for (int i = threadIdx.x; i < LIN_ROWS * K; i += NT) {
+      const int r = i / K, k = i - r * K;
+      float v = (m0 + r < M) ? x[(size_t)(m0 + r) * K + k] : 0.f;
+      xs[i] = act_in ? dm_silu(v) : v;
+    }
+    for (int i = threadIdx.x; i < LIN_COLS * K; i += NT) {
+      const int c = i / K, k = i - c * K;
+      ws[c * (K + 4) + k] = (n0 + c < N) ? w[(size_t)(n0 + c) * K + k] : 0.f;
+    }
   }
   __syncthreads();
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;  // 4 row groups of 4 rows
+  // (the loop is bound by its LDS reads: four k per 16-byte read. The same fused multiply-adds in the same order in
+  // both forms: see fma_acc)
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < K; ++k) {
-    const float wv = ws[c * (K + 1) + k];
+  if (K % 4 == 0) {
+    for (int k = 0; k < K; k += 4) {
+      const f32x4_t wv = *(const f32x4_t*)(ws + c * (K + 4) + k);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += xs[(rg * 4 + r) * K + k] * wv;
+      for (int r = 0; r < 4; ++r) {
+        const f32x4_t xv = *(const f32x4_t*)(xs + (rg * 4 + r) * K + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fma_acc(acc[r], xv[e], wv[e]);
+      }
+    }
+  } else {
+    for (int k = 0; k < K; ++k) {
+      const float wv = ws[c * (K + 4) + k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fma_acc(acc[r], xs[(rg * 4 + r) * K + k], wv);
+    }
   }
   if (n0 + c < N) {
     const float bv = bias ? bias[n0 + c] : 0.f;
@@ -59,7 +128,7 @@ __global__ __launch_bounds__(NT) void linear_bwd_x_kernel(const float* __restric
                                                           const float* __restrict__ dy, float* __restrict__ dx, int M,
                                                           int K, int N, int act_in) {
   __shared__ float sdy[BX_ROWS][BX_CHUNK];
-  __shared__ float sw[BX_CHUNK][BX_COLS];
+  __shared__ __attribute__((aligned(16))) float sw[BX_CHUNK][BX_COLS];
   const int k0 = blockIdx.x * BX_COLS, m0 = blockIdx.y * BX_ROWS;
   const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
   float acc = 0.f;
@@ -69,9 +138,15 @@ __global__ __launch_bounds__(NT) void linear_bwd_x_kernel(const float* __restric
       const int rr = threadIdx.x / BX_CHUNK, nn = threadIdx.x % BX_CHUNK;
       sdy[rr][nn] = (m0 + rr < M && n0 + nn < N) ? dy[(size_t)(m0 + rr) * N + n0 + nn] : 0.f;
     }
-    for (int i = threadIdx.x; i < BX_CHUNK * BX_COLS; i += NT) {
-      const int nn = i / BX_COLS, cc = i % BX_COLS;
-      sw[nn][cc] = (n0 + nn < N && k0 + cc < K) ? w[(size_t)(n0 + nn) * K + k0 + cc] : 0.f;
+    if (K % 4 == 0 && k0 + BX_COLS <= K && aligned16(w)) {
+      stage_tile4(w + (size_t)n0 * K + k0, K, BX_CHUNK, BX_COLS, N - n0, [&](int nn, int cc, f32x4_t v) {
+        *(f32x4_t*)&sw[nn][cc] = v;
+      });
+    } else {
+      for (int i = threadIdx.x; i < BX_CHUNK * BX_COLS; i += NT) {
+        const int nn = i / BX_COLS, cc = i % BX_COLS;
+        sw[nn][cc] = (n0 + nn < N && k0 + cc < K) ? w[(size_t)(n0 + nn) * K + k0 + cc] : 0.f;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -104,8 +179,15 @@ __global__ __launch_bounds__(NT) void linear_bwd_w_kernel(const float* __restric
     }
     __syncthreads();
     if (k < K) {
-#pragma unroll 4
-      for (int mm = 0; mm < mc; ++mm) {
+      int mm = 0;
+      for (; mm + 16 <= mc; mm += 16) {
+        float xv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xv[j] = x[(size_t)(mb + mm + j) * K + k];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc += sdy[mm + j][r] * (act_in ? dm_silu(xv[j]) : xv[j]);
+      }
+      for (; mm < mc; ++mm) {
         float xv = x[(size_t)(mb + mm) * K + k];
         if (act_in) xv = dm_silu(xv);
         acc += sdy[mm][r] * xv;
@@ -152,22 +234,48 @@ __global__ __launch_bounds__(NT) void linear_group_fwd_kernel(const float* __res
   float* ws = lds + LIN_ROWS * K;
   const LinearGroupItem it = g.it[find_item(g, blockIdx.x)];
   const int n0 = (blockIdx.x - it.tile0) * LIN_COLS, m0 = blockIdx.y * LIN_ROWS;
-  for (int i = threadIdx.x; i < LIN_ROWS * K; i += NT) {
-    const int r = i / K, k = i - r * K;
-    float v = (m0 + r < M) ? x[(size_t)(m0 + r) * K + k] : 0.f;
-    xs[i] = act_in ? dm_silu(v) : v;
-  }
-  for (int i = threadIdx.x; i < LIN_COLS * K; i += NT) {
-    const int c = i / K, k = i - c * K;
-    ws[c * (K + 1) + k] = (n0 + c < it.N) ? it.w[(size_t)(n0 + c) * K + k] : 0.f;
+  const bool vec = K % 4 == 0 && aligned16(x) && aligned16(it.w);
+  if (vec) {
+    stage_tile4(x + (size_t)m0 * K, K, LIN_ROWS, K, M - m0, [&](int r, int k, f32x4_t v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xs[r * K + k + e] = act_in ? dm_silu(v[e]) : v[e];
+    });
+    stage_tile4(it.w + (size_t)n0 * K, K, LIN_COLS, K, it.N - n0, [&](int c, int k, f32x4_t v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ws[c * (K + 4) + k + e] = v[e];
+    });
+  } else {
+    for (int i = threadIdx.x; i < LIN_ROWS * K; i += NT) {
+      const int r = i / K, k = i - r * K;
+      float v = (m0 + r < M) ? x[(size_t)(m0 + r) * K + k] : 0.f;
+      xs[i] = act_in ? dm_silu(v) : v;
+    }
+    for (int i = threadIdx.x; i < LIN_COLS * K; i += NT) {
+      const int c = i / K, k = i - c * K;
+      ws[c * (K + 4) + k] = (n0 + c < it.N) ? it.w[(size_t)(n0 + c) * K + k] : 0.f;
+    }
   }
   __syncthreads();
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  // (the loop is bound by its LDS reads: four k per 16-byte read. The same fused multiply-adds in the same order in
+  // both forms: see fma_acc)
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < K; ++k) {
-    const float wv = ws[c * (K + 1) + k];
+  if (K % 4 == 0) {
+    for (int k = 0; k < K; k += 4) {
+      const f32x4_t wv = *(const f32x4_t*)(ws + c * (K + 4) + k);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += xs[(rg * 4 + r) * K + k] * wv;
+      for (int r = 0; r < 4; ++r) {
+        const f32x4_t xv = *(const f32x4_t*)(xs + (rg * 4 + r) * K + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fma_acc(acc[r], xv[e], wv[e]);
+      }
+    }
+  } else {
+    for (int k = 0; k < K; ++k) {
+      const float wv = ws[c * (K + 4) + k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fma_acc(acc[r], xs[(rg * 4 + r) * K + k], wv);
+    }
   }
   if (n0 + c < it.N) {
     const float bv = it.b ? it.b[n0 + c] : 0.f;
@@ -203,13 +311,23 @@ __global__ __launch_bounds__(NT) void linear_group_bwd_x_kernel(const LinearGrou
     for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
   for (int n0 = nb; n0 < min(N, nb + GT_XN); n0 += GT_N) {
     __syncthreads();
-    for (int i = threadIdx.x; i < GT_M * GT_N; i += NT) {
-      const int mm = i / GT_N, nn = i - mm * GT_N;
-      sdy[nn * GT_PITCH + mm] = (m0 + mm < M && n0 + nn < N) ? it.dy[(size_t)(m0 + mm) * N + n0 + nn] : 0.f;
-    }
-    for (int i = threadIdx.x; i < GT_N * GT_K; i += NT) {
-      const int nn = i / GT_K, kk = i - nn * GT_K;
-      sw[i] = (n0 + nn < N && k0 + kk < K) ? it.w[(size_t)(n0 + nn) * K + k0 + kk] : 0.f;
+    if (N % 4 == 0 && K % 4 == 0 && n0 + GT_N <= N && k0 + GT_K <= K && aligned16(it.dy) && aligned16(it.w)) {
+      stage_tile4(it.dy + (size_t)m0 * N + n0, N, GT_M, GT_N, M - m0, [&](int mm, int nn, f32x4_t v) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sdy[(nn + e) * GT_PITCH + mm] = v[e];
+      });
+      stage_tile4(it.w + (size_t)n0 * K + k0, K, GT_N, GT_K, GT_N, [&](int nn, int kk, f32x4_t v) {
+        *(f32x4_t*)(sw + nn * GT_K + kk) = v;
+      });
+    } else {
+      for (int i = threadIdx.x; i < GT_M * GT_N; i += NT) {
+        const int mm = i / GT_N, nn = i - mm * GT_N;
+        sdy[nn * GT_PITCH + mm] = (m0 + mm < M && n0 + nn < N) ? it.dy[(size_t)(m0 + mm) * N + n0 + nn] : 0.f;
+      }
+      for (int i = threadIdx.x; i < GT_N * GT_K; i += NT) {
+        const int nn = i / GT_K, kk = i - nn * GT_K;
+        sw[i] = (n0 + nn < N && k0 + kk < K) ? it.w[(size_t)(n0 + nn) * K + k0 + kk] : 0.f;
+      }
     }
     __syncthreads();
 #pragma unroll 4
@@ -249,8 +367,17 @@ __global__ __launch_bounds__(NT) void linear_group_bwd_x_sum_kernel(const float*
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
   float s = 0.f;
-  if (e < total)
-    for (int q = grp; q < nparts; q += 4) s += part[(size_t)q * total + e];
+  if (e < total) {
+    int q = grp;
+    for (; q + 28 < nparts; q += 32) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(q + 4 * j) * total + e];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; q < nparts; q += 4) s += part[(size_t)q * total + e];
+  }
   if (grp) red[grp - 1][lane] = s;
   __syncthreads();
   if (grp || e >= total) return;
@@ -275,14 +402,24 @@ __global__ __launch_bounds__(NT) void linear_group_bwd_w_kernel(const float* __r
     for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
   for (int mb = 0; mb < M; mb += GT_N) {
     __syncthreads();
-    for (int i = threadIdx.x; i < GT_N * GT_N; i += NT) {
-      const int mm = i / GT_N, nn = i - mm * GT_N;
-      sdy[i] = (mb + mm < M && n0 + nn < N) ? it.dy[(size_t)(mb + mm) * N + n0 + nn] : 0.f;
-    }
-    for (int i = threadIdx.x; i < GT_N * GT_K; i += NT) {
-      const int mm = i / GT_K, kk = i - mm * GT_K;
-      float v = (mb + mm < M && k0 + kk < K) ? x[(size_t)(mb + mm) * K + k0 + kk] : 0.f;
-      sx[i] = act_in ? dm_silu(v) : v;
+    if (N % 4 == 0 && K % 4 == 0 && n0 + GT_N <= N && k0 + GT_K <= K && aligned16(it.dy) && aligned16(x)) {
+      stage_tile4(it.dy + (size_t)mb * N + n0, N, GT_N, GT_N, M - mb, [&](int mm, int nn, f32x4_t v) {
+        *(f32x4_t*)(sdy + mm * GT_N + nn) = v;
+      });
+      stage_tile4(x + (size_t)mb * K + k0, K, GT_N, GT_K, M - mb, [&](int mm, int kk, f32x4_t v) {
+        if (act_in) v = f32x4_t{dm_silu(v[0]), dm_silu(v[1]), dm_silu(v[2]), dm_silu(v[3])};
+        *(f32x4_t*)(sx + mm * GT_K + kk) = v;
+      });
+    } else {
+      for (int i = threadIdx.x; i < GT_N * GT_N; i += NT) {
+        const int mm = i / GT_N, nn = i - mm * GT_N;
+        sdy[i] = (mb + mm < M && n0 + nn < N) ? it.dy[(size_t)(mb + mm) * N + n0 + nn] : 0.f;
+      }
+      for (int i = threadIdx.x; i < GT_N * GT_K; i += NT) {
+        const int mm = i / GT_K, kk = i - mm * GT_K;
+        float v = (mb + mm < M && k0 + kk < K) ? x[(size_t)(mb + mm) * K + k0 + kk] : 0.f;
+        sx[i] = act_in ? dm_silu(v) : v;
+      }
     }
     __syncthreads();
 #pragma unroll 4
@@ -303,10 +440,15 @@ __global__ __launch_bounds__(NT) void linear_group_bwd_w_kernel(const float* __r
     const int n = n0 + ty * 4 + i;
     if (n >= N) continue;
     if (it.dw) {
+      float* dst = it.dw + (size_t)n * K + k0 + tx * 8;
+      if (K % 4 == 0 && k0 + tx * 8 + 8 <= K && aligned16(it.dw)) {
+        const f32x4_t o0 = *(const f32x4_t*)dst, o1 = *(const f32x4_t*)(dst + 4);
+        *(f32x4_t*)dst = f32x4_t{o0[0] + acc[i][0], o0[1] + acc[i][1], o0[2] + acc[i][2], o0[3] + acc[i][3]};
+        *(f32x4_t*)(dst + 4) = f32x4_t{o1[0] + acc[i][4], o1[1] + acc[i][5], o1[2] + acc[i][6], o1[3] + acc[i][7]};
+      } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = k0 + tx * 8 + j;
-        if (k < K) it.dw[(size_t)n * K + k] += acc[i][j];
+        for (int j = 0; j < 8; ++j)
+          if (k0 + tx * 8 + j < K) dst[j] += acc[i][j];
       }
     }
     if (it.db && blockIdx.y == 0 && tx == 0) it.db[n] += bsum[i];
@@ -328,15 +470,34 @@ __global__ void class_embed_add_kernel(float* __restrict__ emb, const float* __r
   emb[i] += table[(size_t)class_index(cls, mask, uncond, b) * E + e];
 }
 // one thread per (table row, feature): the samples that map to the row are added in batch order
+constexpr int CE_CHUNK = 1024;
 __global__ void class_embed_bwd_kernel(const float* __restrict__ demb, float* __restrict__ dtable,
                                        const int64_t* __restrict__ cls, const float* __restrict__ mask, int uncond, int B,
                                        int E) {
+  __shared__ unsigned char mine[CE_CHUNK];
   const int e = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
-  if (e >= E || row == uncond) return;
+  if (row == uncond) return;
   float s = 0.f;
-  for (int b = 0; b < B; ++b)
-    if (class_index(cls, mask, uncond, b) == row) s += demb[(size_t)b * E + e];
-  dtable[(size_t)row * E + e] += s;
+  for (int b0 = 0; b0 < B; b0 += CE_CHUNK) {   // which samples map to this row: looked up once, by all threads together
+    const int nb = min(CE_CHUNK, B - b0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) mine[i] = class_index(cls, mask, uncond, b0 + i) == row;
+    __syncthreads();
+    if (e < E) {
+      int i = 0;
+      for (; i + 8 <= nb; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = mine[i + j] ? demb[(size_t)(b0 + i + j) * E + e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (mine[i + j]) s += v[j];
+      }
+      for (; i < nb; ++i)
+        if (mine[i]) s += demb[(size_t)(b0 + i) * E + e];
+    }
+  }
+  if (e < E) dtable[(size_t)row * E + e] += s;
 }
 
 // ---- 2x resampling, NHWC bf16, one thread per 8 channels of one OUTPUT pixel
@@ -544,7 +705,7 @@ extern "C" int dm_timestep_embed(const int64_t* t, const float* freq, float* out
 extern "C" int dm_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act_in,
                              void* stream) {
   DM_REQUIRE(x && w && y && M > 0 && K > 0 && N > 0, DM_ERR_ARG, "dm_linear_fwd: bad argument");
-  const int lds = (LIN_ROWS * K + LIN_COLS * (K + 1)) * 4;
+  const int lds = (LIN_ROWS * K + LIN_COLS * (K + 4)) * 4;
   DM_REQUIRE(lds <= 65536, DM_ERR_UNSUPPORTED, "dm_linear_fwd: K=%d too large for the embedding-path kernel", K);
   hipLaunchKernelGGL(linear_fwd_kernel, dim3(dm_cdiv(N, LIN_COLS), dm_cdiv(M, LIN_ROWS)), dim3(NT), lds, (hipStream_t)stream,
                      x, w, bias, y, M, K, N, act_in);
@@ -590,7 +751,7 @@ extern "C" int dm_linear_group_fwd(const float* x, const dm_linear_item* items, 
   int rc = fill_group(g, items, P, LIN_COLS, &tiles);
   if (rc) return rc;
   for (int p = 0; p < P; ++p) DM_REQUIRE(items[p].y, DM_ERR_ARG, "dm_linear_group_fwd: layer %d has no output", p);
-  const int lds = (LIN_ROWS * K + LIN_COLS * (K + 1)) * 4;
+  const int lds = (LIN_ROWS * K + LIN_COLS * (K + 4)) * 4;
   DM_REQUIRE(lds <= 65536, DM_ERR_UNSUPPORTED, "dm_linear_group_fwd: K=%d too large", K);
   hipLaunchKernelGGL(linear_group_fwd_kernel, dim3(tiles, dm_cdiv(M, LIN_ROWS)), dim3(NT), lds, (hipStream_t)stream, x, g, M, K,
                      act_in);
