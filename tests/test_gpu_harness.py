@@ -324,3 +324,47 @@ def test_back_to_back_replays_of_one_graph_equal_eager():
             bad.append((i, float(lc)))
     assert not bad, (want, len(bad), bad[:5])
 
+
+
+def test_fp32_operators_beside_matrix_core_kernels():
+    """The embedding path's fp32 kernels give the same bits while bf16 GEMMs (matrix-core kernels of another branch
+    of the same graph) share the compute units as they do alone. Packed fp32 FMAs in the `op_sel:[0,1,0]` form lost
+    a product in lanes 48-63 under exactly this neighbour (80 % of the launches of a build that had them); the
+    kernels' inner loops are written with plain FMAs since."""
+    from dm_hip import ops
+    g = torch.Generator().manual_seed(1)
+    M, K = 8, 64
+    x = torch.randn(M, K, generator=g).to(dev())
+    layers = [(torch.randn(n, K, generator=g).mul(0.1).to(dev()), torch.randn(n, generator=g).mul(0.1).to(dev()))
+              for n in (128, 256, 256, 256, 128)]
+    w1, b1 = torch.randn(256, K, generator=g).mul(0.1).to(dev()), torch.randn(256, generator=g).mul(0.1).to(dev())
+    A = torch.randn(2048, 2048, generator=g).to(dev()).bfloat16()
+
+    def work():
+        return [ops.linear(x, w1, b1, act_in=False)] + ops.linear_group(x, layers, act_in=True)
+
+    with torch.no_grad():
+        want = torch.cat([y.flatten() for y in work()])
+        torch.cuda.synchronize()
+        side, aux = torch.cuda.Stream(), torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        N = 40
+        for phase in ("warm-up", "capture"):
+            outs, keep = [], []
+            graph = ops.new_graph() if phase == "capture" else None
+            with (torch.cuda.graph(graph, stream=side) if graph is not None else torch.cuda.stream(side)):
+                aux.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(aux):
+                    for _ in range(N):
+                        keep.append(A @ A)
+                for _ in range(N):
+                    outs.append(work())
+                torch.cuda.current_stream().wait_stream(aux)
+            torch.cuda.synchronize()
+        bad = 0
+        for _ in range(10):
+            graph.replay()
+            graph.replay()
+            torch.cuda.synchronize()
+            bad += sum(not torch.equal(torch.cat([y.flatten() for y in ys]), want) for ys in outs)
+    assert bad == 0, f"{bad} of {10 * N} results differ from the quiet launch"

@@ -22,6 +22,23 @@ def test_library_exports_every_declared_symbol():
     assert dm_hip.lib.dm_abi_version() == 3
 
 
+def test_no_packed_fp32_instruction_takes_its_low_lane_from_the_second_sources_high_register():
+    """The built library's device code holds no v_pk_{fma,mul,add}_f32 with op_sel:[x,1,..]: the form that lost a
+    product beside matrix-core kernels on MI355X (tools/check_packed_forms.py has the story; the GPU suite's
+    test_fp32_operators_beside_matrix_core_kernels is the run-time side of this check)."""
+    import importlib.util
+    import shutil
+    import dm_hip
+    spec = importlib.util.spec_from_file_location("check_packed_forms", os.path.join(ROOT, "tools", "check_packed_forms.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not shutil.which(os.path.join(mod.LLVM, "llvm-objdump")):
+        pytest.skip("no ROCm LLVM tools to disassemble with")
+    hits, objects = mod.find_forms(dm_hip.LIB_PATH)
+    assert objects >= 10, objects
+    assert not hits, hits[:8]
+
+
 def test_status_and_error_text_without_gpu():
     import dm_hip
     rc = dm_hip.lib.dm_timestep_embed(None, None, None, 0, 0, None)
