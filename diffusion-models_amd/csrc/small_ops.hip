@@ -60,56 +60,61 @@ __device__ __forceinline__ void fma_acc(float& acc, float a, float b) {
   asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
 }
 
-// ---- y[m][n] = sum_k f(x[m][k]) w[n][k] + bias[n]; block = 64 columns x 16 rows
-constexpr int LIN_ROWS = 16, LIN_COLS = 64;
-__global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ y, int M,
-                                                        int K, int N, int act_in) {
+// ---- y[m][n] = sum_k f(x[m][k]) w[n][k] + bias[n]; block = 64 columns x 16 rows, K walked through LDS in chunks of at
+// most LIN_KC (one chunk for the widths the UNet configurations use; the sum runs over k in ascending order either way)
+constexpr int LIN_ROWS = 16, LIN_COLS = 64, LIN_KC = 128;
+__device__ __forceinline__ void linear_tile(const float* __restrict__ x, const float* __restrict__ w,
+                                            const float* __restrict__ bias, float* __restrict__ y, int M, int K, int N,
+                                            int n0, int m0, int act_in) {
   extern __shared__ float lds[];
-  float* xs = lds;                    // [LIN_ROWS][K]
-  float* ws = lds + LIN_ROWS * K;     // [LIN_COLS][K+4]: 16-byte reads along k, eight lanes cover the 32 banks
-  const int n0 = blockIdx.x * LIN_COLS, m0 = blockIdx.y * LIN_ROWS;
+  const int kc = min(K, LIN_KC);
+  float* xs = lds;                     // [LIN_ROWS][kc]
+  float* ws = lds + LIN_ROWS * kc;     // [LIN_COLS][kc+4]: 16-byte reads along k, eight lanes cover the 32 banks
   const bool vec = K % 4 == 0 && aligned16(x) && aligned16(w);
-  if (vec) {
-    stage_tile4(x + (size_t)m0 * K, K, LIN_ROWS, K, M - m0, [&](int r, int k, f32x4_t v) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) xs[r * K + k + e] = act_in ? dm_silu(v[e]) : v[e];
-    });
-    stage_tile4(w + (size_t)n0 * K, K, LIN_COLS, K, N - n0, [&](int c, int k, f32x4_t v) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ws[c * (K + 4) + k + e] = v[e];
-    });
-  } else {
-    for (int i = threadIdx.x; i < LIN_ROWS * K; i += NT) {
-      const int r = i / K, k = i - r * K;
-      float v = (m0 + r < M) ? x[(size_t)(m0 + r) * K + k] : 0.f;
-      xs[i] = act_in ? dm_silu(v) : v;
-    }
-    for (int i = threadIdx.x; i < LIN_COLS * K; i += NT) {
-      const int c = i / K, k = i - c * K;
-      ws[c * (K + 4) + k] = (n0 + c < N) ? w[(size_t)(n0 + c) * K + k] : 0.f;
-    }
-  }
-  __syncthreads();
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;  // 4 row groups of 4 rows
-  // (the loop is bound by its LDS reads: four k per 16-byte read. The same fused multiply-adds in the same order in
-  // both forms: see fma_acc)
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (K % 4 == 0) {
-    for (int k = 0; k < K; k += 4) {
-      const f32x4_t wv = *(const f32x4_t*)(ws + c * (K + 4) + k);
+  for (int k0 = 0; k0 < K; k0 += kc) {
+    const int kn = min(kc, K - k0);
+    if (k0) __syncthreads();
+    if (vec) {
+      stage_tile4(x + (size_t)m0 * K + k0, K, LIN_ROWS, kn, M - m0, [&](int r, int k, f32x4_t v) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x4_t xv = *(const f32x4_t*)(xs + (rg * 4 + r) * K + k);
+        for (int e = 0; e < 4; ++e) xs[r * kc + k + e] = act_in ? dm_silu(v[e]) : v[e];
+      });
+      stage_tile4(w + (size_t)n0 * K + k0, K, LIN_COLS, kn, N - n0, [&](int cc, int k, f32x4_t v) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) fma_acc(acc[r], xv[e], wv[e]);
+        for (int e = 0; e < 4; ++e) ws[cc * (kc + 4) + k + e] = v[e];
+      });
+    } else {
+      for (int i = threadIdx.x; i < LIN_ROWS * kn; i += NT) {
+        const int r = i / kn, k = i - r * kn;
+        float v = (m0 + r < M) ? x[(size_t)(m0 + r) * K + k0 + k] : 0.f;
+        xs[r * kc + k] = act_in ? dm_silu(v) : v;
+      }
+      for (int i = threadIdx.x; i < LIN_COLS * kn; i += NT) {
+        const int cc = i / kn, k = i - cc * kn;
+        ws[cc * (kc + 4) + k] = (n0 + cc < N) ? w[(size_t)(n0 + cc) * K + k0 + k] : 0.f;
       }
     }
-  } else {
-    for (int k = 0; k < K; ++k) {
-      const float wv = ws[c * (K + 4) + k];
+    __syncthreads();
+    // (the loop is bound by its LDS reads: four k per 16-byte read. The same fused multiply-adds in the same order in
+    // both forms: see fma_acc. kn % 4 == 0 implies kc % 4 == 0, so every row starts on a 16-byte boundary)
+    if (kn % 4 == 0) {
+      for (int k = 0; k < kn; k += 4) {
+        const f32x4_t wv = *(const f32x4_t*)(ws + c * (kc + 4) + k);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) fma_acc(acc[r], xs[(rg * 4 + r) * K + k], wv);
+        for (int r = 0; r < 4; ++r) {
+          const f32x4_t xv = *(const f32x4_t*)(xs + (rg * 4 + r) * kc + k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fma_acc(acc[r], xv[e], wv[e]);
+        }
+      }
+    } else {
+      for (int k = 0; k < kn; ++k) {
+        const float wv = ws[c * (kc + 4) + k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fma_acc(acc[r], xs[(rg * 4 + r) * kc + k], wv);
+      }
     }
   }
   if (n0 + c < N) {
@@ -120,6 +125,15 @@ __global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict_
       if (m < M) y[(size_t)m * N + n0 + c] = acc[r] + bv;
     }
   }
+}
+__host__ __device__ constexpr int linear_tile_lds_bytes(int K) {
+  return (LIN_ROWS * (K < LIN_KC ? K : LIN_KC) + LIN_COLS * ((K < LIN_KC ? K : LIN_KC) + 4)) * 4;
+}
+
+__global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int M,
+                                                        int K, int N, int act_in) {
+  linear_tile(x, w, bias, y, M, K, N, blockIdx.x * LIN_COLS, blockIdx.y * LIN_ROWS, act_in);
 }
 
 // dx[m][k] = f'(x[m][k]) * sum_n dy[m][n] w[n][k]; block = 4 rows x 64 columns, n streamed through LDS in chunks
@@ -229,62 +243,8 @@ __device__ __forceinline__ int find_item(const LinearGroup& g, int tile) {
 
 __global__ __launch_bounds__(NT) void linear_group_fwd_kernel(const float* __restrict__ x, const LinearGroup g, int M, int K,
                                                               int act_in) {
-  extern __shared__ float lds[];
-  float* xs = lds;
-  float* ws = lds + LIN_ROWS * K;
   const LinearGroupItem it = g.it[find_item(g, blockIdx.x)];
-  const int n0 = (blockIdx.x - it.tile0) * LIN_COLS, m0 = blockIdx.y * LIN_ROWS;
-  const bool vec = K % 4 == 0 && aligned16(x) && aligned16(it.w);
-  if (vec) {
-    stage_tile4(x + (size_t)m0 * K, K, LIN_ROWS, K, M - m0, [&](int r, int k, f32x4_t v) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) xs[r * K + k + e] = act_in ? dm_silu(v[e]) : v[e];
-    });
-    stage_tile4(it.w + (size_t)n0 * K, K, LIN_COLS, K, it.N - n0, [&](int c, int k, f32x4_t v) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ws[c * (K + 4) + k + e] = v[e];
-    });
-  } else {
-    for (int i = threadIdx.x; i < LIN_ROWS * K; i += NT) {
-      const int r = i / K, k = i - r * K;
-      float v = (m0 + r < M) ? x[(size_t)(m0 + r) * K + k] : 0.f;
-      xs[i] = act_in ? dm_silu(v) : v;
-    }
-    for (int i = threadIdx.x; i < LIN_COLS * K; i += NT) {
-      const int c = i / K, k = i - c * K;
-      ws[c * (K + 4) + k] = (n0 + c < it.N) ? it.w[(size_t)(n0 + c) * K + k] : 0.f;
-    }
-  }
-  __syncthreads();
-  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  // (the loop is bound by its LDS reads: four k per 16-byte read. The same fused multiply-adds in the same order in
-  // both forms: see fma_acc)
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (K % 4 == 0) {
-    for (int k = 0; k < K; k += 4) {
-      const f32x4_t wv = *(const f32x4_t*)(ws + c * (K + 4) + k);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x4_t xv = *(const f32x4_t*)(xs + (rg * 4 + r) * K + k);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) fma_acc(acc[r], xv[e], wv[e]);
-      }
-    }
-  } else {
-    for (int k = 0; k < K; ++k) {
-      const float wv = ws[c * (K + 4) + k];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) fma_acc(acc[r], xs[(rg * 4 + r) * K + k], wv);
-    }
-  }
-  if (n0 + c < it.N) {
-    const float bv = it.b ? it.b[n0 + c] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + rg * 4 + r;
-      if (m < M) it.y[(size_t)m * it.N + n0 + c] = acc[r] + bv;
-    }
-  }
+  linear_tile(x, it.w, it.b, it.y, M, K, it.N, (blockIdx.x - it.tile0) * LIN_COLS, blockIdx.y * LIN_ROWS, act_in);
 }
 
 // Backward of the grouped linear as two register-tiled fp32 GEMMs (the layers differ only in N, so the launch grid
@@ -705,8 +665,7 @@ extern "C" int dm_timestep_embed(const int64_t* t, const float* freq, float* out
 extern "C" int dm_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act_in,
                              void* stream) {
   DM_REQUIRE(x && w && y && M > 0 && K > 0 && N > 0, DM_ERR_ARG, "dm_linear_fwd: bad argument");
-  const int lds = (LIN_ROWS * K + LIN_COLS * (K + 4)) * 4;
-  DM_REQUIRE(lds <= 65536, DM_ERR_UNSUPPORTED, "dm_linear_fwd: K=%d too large for the embedding-path kernel", K);
+  const int lds = linear_tile_lds_bytes(K);
   hipLaunchKernelGGL(linear_fwd_kernel, dim3(dm_cdiv(N, LIN_COLS), dm_cdiv(M, LIN_ROWS)), dim3(NT), lds, (hipStream_t)stream,
                      x, w, bias, y, M, K, N, act_in);
   DM_CHECK_LAUNCH();
@@ -751,8 +710,7 @@ extern "C" int dm_linear_group_fwd(const float* x, const dm_linear_item* items, 
   int rc = fill_group(g, items, P, LIN_COLS, &tiles);
   if (rc) return rc;
   for (int p = 0; p < P; ++p) DM_REQUIRE(items[p].y, DM_ERR_ARG, "dm_linear_group_fwd: layer %d has no output", p);
-  const int lds = (LIN_ROWS * K + LIN_COLS * (K + 4)) * 4;
-  DM_REQUIRE(lds <= 65536, DM_ERR_UNSUPPORTED, "dm_linear_group_fwd: K=%d too large", K);
+  const int lds = linear_tile_lds_bytes(K);
   hipLaunchKernelGGL(linear_group_fwd_kernel, dim3(tiles, dm_cdiv(M, LIN_ROWS)), dim3(NT), lds, (hipStream_t)stream, x, g, M, K,
                      act_in);
   DM_CHECK_LAUNCH();

@@ -368,3 +368,62 @@ def test_fp32_operators_beside_matrix_core_kernels():
             torch.cuda.synchronize()
             bad += sum(not torch.equal(torch.cat([y.flatten() for y in ys]), want) for ys in outs)
     assert bad == 0, f"{bad} of {10 * N} results differ from the quiet launch"
+
+
+def test_fp32_gradient_kernels_beside_matrix_core_kernels():
+    """The same for the gradients of the embedding path (grouped and plain linear, class table) and the first
+    convolution's weight gradient, at the full-size model's batch and a wide embedding: computed beside bf16 GEMMs of
+    another branch of the graph they equal, bit for bit, the gradients of a quiet launch."""
+    from dm_hip import ops
+    g = torch.Generator().manual_seed(1)
+    M, K = 128, 512
+    widths = [128, 256, 512, 256]
+    d = dev()
+    x = torch.randn(M, K, generator=g).to(d).requires_grad_()
+    layers = [(torch.randn(n, K, generator=g).mul(0.05).to(d).requires_grad_(),
+               torch.randn(n, generator=g).mul(0.1).to(d).requires_grad_()) for n in widths]
+    gys = [torch.randn(M, n, generator=g).to(d) for n in widths]
+    w1 = torch.randn(K, 128, generator=g).mul(0.05).to(d).requires_grad_()
+    b1 = torch.randn(K, generator=g).mul(0.1).to(d).requires_grad_()
+    x1 = torch.randn(M, 128, generator=g).to(d).requires_grad_()
+    gy1 = torch.randn(M, K, generator=g).to(d)
+    table = torch.randn(11, K, generator=g).to(d).requires_grad_()
+    cls = torch.randint(0, 10, (M,), generator=g).to(d)
+    mask = (torch.rand(M, generator=g) < 0.2).float().to(d)
+    img = torch.randn(M, 3, 32, 32, generator=g).to(d)
+    w_in = torch.randn(128, 3, 3, 3, generator=g).mul(0.1).to(d).requires_grad_()
+    b_in = torch.zeros(128, device=d).requires_grad_()
+    A = torch.randn(2048, 2048, generator=g).to(d).bfloat16()
+    params = [x, x1, w1, b1, table, w_in, b_in] + [t for wb in layers for t in wb]
+
+    def work():
+        ys = ops.linear_group(x, layers, act_in=True)
+        e = ops.class_embed_add(ops.linear(x1, w1, b1, act_in=True), table, cls, mask, 10)
+        h = ops.in_conv(img, w_in, b_in)
+        loss = sum((y * gy).sum() for y, gy in zip(ys, gys)) + (e * gy1).sum() + h.float().square().mean()
+        return torch.autograd.grad(loss, params)
+
+    want = torch.cat([t.flatten() for t in work()])
+    torch.cuda.synchronize()
+    side, aux = torch.cuda.Stream(), torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    N = 10
+    for phase in ("warm-up", "capture"):
+        outs, keep = [], []
+        graph = ops.new_graph() if phase == "capture" else None
+        with (torch.cuda.graph(graph, stream=side) if graph is not None else torch.cuda.stream(side)):
+            aux.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(aux), torch.no_grad():
+                for _ in range(4 * N):
+                    keep.append(A @ A)
+            for _ in range(N):
+                outs.append(work())
+            torch.cuda.current_stream().wait_stream(aux)
+        torch.cuda.synchronize()
+    bad = 0
+    for _ in range(6):
+        graph.replay()
+        graph.replay()
+        torch.cuda.synchronize()
+        bad += sum(not torch.equal(torch.cat([t.flatten() for t in grads]), want) for grads in outs)
+    assert bad == 0, f"{bad} of {6 * N} gradient sets differ from the quiet launch"

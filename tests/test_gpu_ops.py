@@ -715,8 +715,12 @@ def _attention_case(B, L, H, D):
     assert rel_err(qd.grad.float(), qr.grad) < BF16_BWD
 
 
-@pytest.mark.parametrize("M,K,N,act", [(8, 64, 128, False), (128, 128, 1024, True), (5, 64, 64, True), (33, 128, 192, False)])
+@pytest.mark.parametrize("M,K,N,act", [(8, 64, 128, False), (128, 128, 1024, True), (5, 64, 64, True), (33, 128, 192, False),
+                                       (9, 30, 70, True), (20, 256, 192, True), (7, 512, 130, False), (17, 203, 64, True),
+                                       (6, 260, 64, False)])
 def test_linear_fwd_bwd(M, K, N, act):
+    """(the cases from K = 203 up walk the input features through LDS in more than one chunk; K = 30, 203: widths that
+    are not multiples of 4 take the scalar staging and inner loops)"""
     from dm_hip import ops
     rs = np.random.RandomState(M + K + N)
     x, w, b = rnd(rs, M, K), rnd(rs, N, K, scale=K ** -0.5), rnd(rs, N, scale=0.1)
@@ -730,6 +734,34 @@ def test_linear_fwd_bwd(M, K, N, act):
     assert rel_err(y, y_ref) < 1e-5
     y.backward(gy.to(d))
     assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(wd.grad, wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("M,K,widths", [(8, 64, (128, 256, 64)), (128, 128, (128, 256, 512, 512, 1024)), (5, 30, (70, 64)),
+                                        (16, 256, (128, 384)), (3, 516, (64, 200))])
+def test_linear_group_fwd_bwd(M, K, widths):
+    """All projections of one input in one launch each way (what a UNet forward does with its emb_proj layers), against
+    torch fp32 layer by layer; the input's gradient is the sum over the layers. The last two cases have more input
+    features than one LDS chunk of the forward kernel holds."""
+    from dm_hip import ops
+    rs = np.random.RandomState(M + K + len(widths))
+    x = rnd(rs, M, K)
+    ws = [rnd(rs, n, K, scale=K ** -0.5) for n in widths]
+    bs = [rnd(rs, n, scale=0.1) for n in widths]
+    gys = [rnd(rs, M, n) for n in widths]
+    xr = x.clone().requires_grad_(True)
+    wr, br = [w.clone().requires_grad_(True) for w in ws], [b.clone().requires_grad_(True) for b in bs]
+    refs = [F.linear(F.silu(xr), w, b) for w, b in zip(wr, br)]
+    sum((y * gy).sum() for y, gy in zip(refs, gys)).backward()
+    d = dev()
+    xd = x.to(d).requires_grad_(True)
+    wd, bd = [w.to(d).requires_grad_(True) for w in ws], [b.to(d).requires_grad_(True) for b in bs]
+    ys = ops.linear_group(xd, list(zip(wd, bd)), act_in=True)
+    for y, ref in zip(ys, refs):
+        assert rel_err(y, ref) < 1e-5
+    sum((y * gy.to(d)).sum() for y, gy in zip(ys, gys)).backward()
+    assert rel_err(xd.grad, xr.grad) < 1e-5
+    for a, b in zip(wd + bd, wr + br):
+        assert rel_err(a.grad, b.grad) < 1e-5
 
 
 def test_timestep_embedding_matches_reference_vectors():
