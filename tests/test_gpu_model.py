@@ -248,7 +248,8 @@ def test_unet_vs_reference(name, cfg):
     assert worst < 1.0, worst   # sampled entries off by less than 4 rms-entries * tolerance scale
 
 
-@pytest.mark.parametrize("name,cfg,B", [("tiny", TINY_CFG, 4), ("tiny_attnblocks", TINY_ATTN_CFG, 6)])
+@pytest.mark.parametrize("name,cfg,B", [("tiny", TINY_CFG, 4), ("tiny_attnblocks", TINY_ATTN_CFG, 6),
+                                        ("tiny_wide_embedding", dict(TINY_CFG, embedding_dim=320, time_encoding_dim=256), 3)])
 def test_every_parameter_gradient_vs_oracle(name, cfg, B):
     """One training-step backward through the HIP kernels against the fp32 CPU oracle on the same inputs: the gradient
     of EVERY parameter as a relative L2 error (the reference fixtures above only hold norms and 16 entries each).
