@@ -50,12 +50,15 @@ __device__ __forceinline__ bool aligned16(const void* p) { return ((uintptr_t)p 
 
 // acc += a * b as ONE v_fmac_f32, spelled out. Left to the compiler, the forward kernels' inner loops become packed
 // v_pk_fma_f32 on pairs of rows, and for the odd elements of a 16-byte LDS read in the form `op_sel:[0,1,0]` (the low
-// lane multiplies by the HIGH register of the second source pair). On MI355X that form was measured to drop the low
-// lane's product in lanes 48-63 now and then while a matrix-core kernel of another stream shares the compute unit: one
-// term x[m][k] * w[n][k] missing from 16 neighbouring outputs of an even row, in 80 % of the launches beside a bf16 GEMM
-// and in a few percent of training steps (beside the first convolutions); the same loop with plain FMAs never did
-// (tools/experiments/repro_linear_group.py). The loops are bound by their LDS reads, so the unpacked form costs
-// nothing. It also fixes the contraction: a row's result must not depend on its place in the tile.
+// lane multiplies by the HIGH register of the second source pair). On MI355X that form - and v_pk_mul_f32 /
+// v_pk_add_f32 with op_sel:[0,1]; no other operand-select form - loses the low lane's product in lanes 48-63 now and
+// then while waves of ANOTHER kernel that issue matrix-core instructions and direct-to-LDS buffer loads share the
+// compute unit (this library's 3x3 convolutions and the vendor's 16-bit GEMMs are such kernels): one term
+// x[m][k] * w[n][k] missing from 16 neighbouring outputs of an even row, in 80 % of the launches beside a bf16 GEMM and
+// in a few percent of training steps; the same loop with plain FMAs never did (tools/experiments/pk_forms_repro.hip is
+// a stand-alone reproducer, repro_linear_group.py the one with these kernels). The loops are bound by their LDS
+// reads, so the unpacked form costs nothing. It also fixes the contraction: a row's result must not depend on its
+// place in the tile.
 __device__ __forceinline__ void fma_acc(float& acc, float a, float b) {
   asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
 }

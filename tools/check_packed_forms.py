@@ -1,11 +1,14 @@
 """Scan the device code of a built libdm_hip.so for packed fp32 instructions whose LOW lane takes the HIGH register of
 the second source (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with op_sel:[x,1,...]).
 
-That form, chosen by the compiler for the odd elements of a 16-byte LDS read in an fp32 inner loop, was measured on
-MI355X to lose the low lane's product in lanes 48-63 while a matrix-core kernel of another stream shared the compute
-unit (tools/experiments/repro_linear_group.py reproduces it with the kernels of tools/experiments/
-small_ops_fast_staging.hip.txt). Kernels that must be exact write such loops with explicit v_fmac_f32 (fma_acc in
-csrc/small_ops.hip); this check keeps the form from coming back unnoticed after a compiler or source change.
+That form was measured on MI355X to lose the low lane's product in lanes 48-63 while waves of another kernel that
+issue matrix-core instructions and direct-to-LDS buffer loads shared the compute unit (the vendor's 16-bit GEMMs, this
+library's 3x3 convolutions). tools/experiments/pk_forms_repro.hip is a stand-alone reproducer that walks through the
+operand-select forms: op_sel:[0,1,0] (fma) and op_sel:[0,1] (mul, add) fail, every other form - op_sel:[1,0,0],
+[0,0,1], [1,1,0], all op_sel_hi forms, v_pk_mov_b32 - does not; this check flags any op_sel with the second bit set.
+The compiler chooses the form for the odd elements of a 16-byte vector that multiply a pair of rows (an fp32 inner loop
+fed by 16-byte LDS reads); kernels that must be exact write such loops with explicit v_fmac_f32 (fma_acc in
+csrc/small_ops.hip). This check keeps the form from coming back unnoticed after a compiler or source change.
 
   python tools/check_packed_forms.py [path/to/libdm_hip.so]      exit status 1 and a list of kernels if any is found
 """
