@@ -13,6 +13,8 @@ counter, which also writes the next step's t) and, for DDPM, the noise draw: a s
 import weakref
 from typing import Callable, Dict, Optional, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -151,9 +153,11 @@ def interleaved_pred_fn(model, cond: Optional[torch.Tensor], guidance_scale: flo
         cur = torch.cuda.current_stream()
         out = torch.empty_like(z, dtype=torch.float32)
         # the network's own side stream for the embedding path stays off inside the chains: a fork inside a forked
-        # stream, twice in one capture, crashes the HIP runtime's graph capture (ROCm 7.2), and the other chain already
-        # fills the gaps it would fill
-        emb_side, ops.EMB_SIDE_STREAM = ops.EMB_SIDE_STREAM, False
+        # stream, once per chain in one capture, ends in a segmentation fault of the process (ROCm 7.2;
+        # DM_CHAIN_EMB_SIDE=1 switches it on to reproduce that), and the other chain already fills the gaps it would fill
+        emb_side = ops.EMB_SIDE_STREAM
+        if os.environ.get("DM_CHAIN_EMB_SIDE", "0") != "1":
+            ops.EMB_SIDE_STREAM = False
         try:
             for s, (lo, hi), f in zip(streams, bounds, fns[B]):
                 if hi == lo:
