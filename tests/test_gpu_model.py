@@ -249,16 +249,35 @@ def test_unet_vs_reference(name, cfg):
 
 
 @pytest.mark.parametrize("name,cfg,B", [("tiny", TINY_CFG, 4), ("tiny_attnblocks", TINY_ATTN_CFG, 6),
-                                        ("tiny_wide_embedding", dict(TINY_CFG, embedding_dim=320, time_encoding_dim=256), 3)])
+                                        ("tiny_wide_embedding", dict(TINY_CFG, embedding_dim=320, time_encoding_dim=256), 3),
+                                        # pooled / nearest resampling without convolutions, three levels, two blocks per
+                                        # level, no class table, no attention in the middle, one image
+                                        ("three_levels_plain_resampling", dict(
+                                            TINY_CFG, down_block_types=["UNetDownBlock"] * 3, up_block_types=["UNetUpBlock"] * 3,
+                                            block_out_channels=[64, 128, 128], n_blocks_per_layer=2, mid_attention=False,
+                                            n_class_embeddings=None, downsample_use_conv=False, upsample_use_conv=False,
+                                            embedding_mixing="addition"), 1),
+                                        # 8 groups of 16 / 32 channels, attention heads of 16 in every stage, odd batch
+                                        ("wide_groups_heads16", dict(
+                                            TINY_ATTN_CFG, down_block_types=["UNetAttnDownBlock"] * 2,
+                                            up_block_types=["UNetAttnUpBlock"] * 2, block_out_channels=[128, 256],
+                                            norm_groups=8, n_dim_attention_head=16), 5),
+                                        # attention heads of 32 and 64 (the kernels off the matrix cores)
+                                        ("heads32", dict(TINY_ATTN_CFG, n_dim_attention_head=32), 3),
+                                        ("heads64", dict(TINY_ATTN_CFG, n_dim_attention_head=64), 2)])
 def test_every_parameter_gradient_vs_oracle(name, cfg, B):
     """One training-step backward through the HIP kernels against the fp32 CPU oracle on the same inputs: the gradient
     of EVERY parameter as a relative L2 error (the reference fixtures above only hold norms and 16 entries each).
-    bf16 activations through ~40 layers: every parameter within 8 %, half of them within 2 %."""
+    bf16 activations through ~40 layers: every parameter within 8 %, half of them within 2 % (3 % for the deepest case).
+    The cases beyond the first two walk through constructor switches no reference fixture covers."""
     from tests.parity import smoke_check
     e_loss, errs = smoke_check(cfg=cfg, seed=910, B=B)
     v = np.array(sorted(errs.values()))
     print(f"{name}: {len(v)} parameters, median {np.median(v):.3e}, p90 {np.percentile(v, 90):.3e}, max {v.max():.3e}")
-    assert len(v) > 50 and np.median(v) < 2e-2 and e_loss < 5e-3
+    # (the three-level network is twice as deep and sees ONE image: rounding noise grows with the number of bf16 layers a
+    # gradient passes and is not averaged over a batch)
+    median_bound = 3e-2 if name == "three_levels_plain_resampling" else 2e-2
+    assert len(v) > 50 and np.median(v) < median_bound and v.max() < 8e-2 and e_loss < 5e-3
 
 
 def test_classifier_free_guidance_branches():
