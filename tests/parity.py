@@ -116,7 +116,7 @@ def max_abs(a, b):
     return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
 
 
-def smoke_check(cfg=None, seed=900, B=4, tol_loss=2e-2, tol_grad=8e-2):
+def smoke_check(cfg=None, seed=900, B=4, tol_loss=2e-2, tol_grad=8e-2, hw=(16, 16)):
     """One tiny UNet training step on cuda:0 through the HIP kernels, checked against the CPU oracle: the loss and the
     gradient of EVERY parameter (relative L2 error per parameter). Returns (loss error, {name: gradient error})."""
     from modeling import get_model
@@ -131,10 +131,10 @@ def smoke_check(cfg=None, seed=900, B=4, tol_loss=2e-2, tol_grad=8e-2):
     model.load_state_dict(sd)
     model.to(dev).train()
     rs = np.random.RandomState(seed + 1)
-    x = T(rs.uniform(-1, 1, size=(B, 3, 16, 16)).astype(np.float32))
+    x = T(rs.uniform(-1, 1, size=(B, 3) + tuple(hw)).astype(np.float32))
     cls = T(rs.randint(0, 10, size=(B,)).astype(np.int64))
     mask = T((rs.uniform(size=(B,)) < 0.3).astype(np.float32))
-    eps = T(rs.standard_normal((B, 3, 16, 16)).astype(np.float32))
+    eps = T(rs.standard_normal((B, 3) + tuple(hw)).astype(np.float32))
     t = T(rs.randint(0, 1000, size=(B,)).astype(np.int64))
     sched = get_scheduler("beta", schedule="cosine")
 

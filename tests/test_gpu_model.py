@@ -280,6 +280,17 @@ def test_every_parameter_gradient_vs_oracle(name, cfg, B):
     assert len(v) > 50 and np.median(v) < median_bound and v.max() < 8e-2 and e_loss < 5e-3
 
 
+@pytest.mark.parametrize("hw,B", [((8, 24), 3), ((12, 12), 4), ((20, 12), 2), ((32, 16), 2)])
+def test_image_sizes_that_are_not_square_or_powers_of_two_vs_oracle(hw, B):
+    """The network is convolutional: any image whose sides the down path can halve. Loss and every parameter gradient
+    against the oracle for wide, tall and 12-pixel images (rows that do not fill the kernels' 16- and 64-pixel tiles)."""
+    from tests.parity import smoke_check
+    e_loss, errs = smoke_check(cfg=TINY_ATTN_CFG, seed=930 + hw[0], B=B, hw=hw)
+    v = np.array(sorted(errs.values()))
+    print(f"{hw}: {len(v)} parameters, median {np.median(v):.3e}, max {v.max():.3e}")
+    assert len(v) > 50 and np.median(v) < 2.5e-2 and v.max() < 8e-2 and e_loss < 5e-3
+
+
 def test_classifier_free_guidance_branches():
     from modeling import get_model
     g = golden("unet_tiny_cfg.npz")
